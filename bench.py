@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s polygonized + achieved HBM GB/s on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete extraction (the whole GenerateData() path: classify, count,
+scan, emit, projection, triangle split) of a volume already resident in HBM.
+Workload at N=1: BASELINE.json configs[3], the 1024^3 float32 Marschner-Lobb volume,
+iso 0.5, triangles + vertex projection on (thr 0.002, step 0.25, relax 0.95, 50 steps).
+For N>1 each rank owns one such 1024^3 block of a 1024x1024x(1024 N) volume (the block
+repeats along z): Z-slabs, 8-slice halo exchanged over RCCL every step, one all-gather
+of the per-rank (points, cells) counts -> weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def generate_block(pkg, torch, workload, n, lo, hi, period, device):
+    """Slices [lo, hi) of the global volume, generated in HBM in chunks (float64 temporaries)."""
+    chunks = []
+    step = max(1, (1 << 26) // (n * n))
+    for a in range(lo, hi, step):
+        b = min(a + step, hi)
+        if workload == "marschner_lobb":
+            chunks.append(pkg.volumes.marschner_lobb(n, a, b, xp=torch, device=device, period=period))
+        elif workload == "sphere":
+            assert period is None
+            chunks.append(pkg.volumes.sphere_sdf(n, a, b, xp=torch, device=device))
+        elif workload == "noise":
+            chunks.append(pkg.volumes.gradient_noise(n, n, n * 1000000, a, b, xp=torch, device=device))
+        else:
+            raise ValueError(workload)
+    return torch.cat(chunks, 0).contiguous()
+
+
+WORKLOADS = {
+    # name: (dtype, iso, threshold)
+    "marschner_lobb": (np.float32, 0.5, 0.002),
+    "sphere": (np.float32, 0.0, 0.05),
+    "noise": (np.uint8, 128, 0.5),
+}
+
+
+def cpu_baseline(pkg, torch, args, device):
+    """The oracle restatement of the reference ("port"), timed on this box's host cores on a
+    bounded sample of the same workload (the reference itself needs ITK)."""
+    oracle = graft.load_oracle()
+    oracle.build()
+    n = args.cpu_sample
+    dtype, iso, thr = WORKLOADS[args.workload]
+    vol = generate_block(pkg, torch, args.workload, n, 0, n, None, device).cpu().numpy()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    m = oracle.run(vol, iso, triangles=True, project=True, threshold=thr, step=0.25, relax=0.95, max_steps=50,
+                   gradient_threads=cores, faithful_cells=True)
+    dt = time.perf_counter() - t0
+    secs = m.info["seconds_gradient"] + m.info["seconds_sweep"]
+    return {
+        "value": round(n ** 3 / secs / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+        "sample": "%s %d^3 %s (same generator and parameters as the GPU workload, 1/%d of its voxels); "
+                  "sweep single-threaded like the reference, gradient pre-pass on %d threads like ITK; "
+                  "%.1f s gradient + %.1f s sweep, %d points / %d cells; wall %.1f s" % (
+                      args.workload, n, np.dtype(dtype).name, max(1, (args.size // n) ** 3), cores,
+                      m.info["seconds_gradient"], m.info["seconds_sweep"], len(m.points), len(m.cells), dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--workload", default="marschner_lobb", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the cube the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--no-project", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
+            args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    pkg = graft.load_package()
+    pkg._abi.build()
+    from midas_journal_740_amd.distributed import ShardedExtractor
+
+    n = args.size
+    dtype, iso, thr = WORKLOADS[args.workload]
+    gnz = n * world
+    ex = pkg.Extractor(local_rank)
+    sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world)
+    period = n if world > 1 else None
+    if args.workload == "sphere" and world > 1:
+        raise SystemExit("sphere workload is single-GPU only")
+    buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
+    if world > 1:       # halos arrive through the exchange, every step
+        buf[:sh.z0 - sh.lo].zero_()
+        buf[sh.z1 - sh.lo:].zero_()
+    prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
+                          max_steps=50)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = sh.extract(buf, prm)
+    stage_keys = ["ms_classify", "ms_count", "ms_scan", "ms_emit", "ms_project", "ms_triangulate", "ms_total"]
+    acc = {k: 0.0 for k in stage_keys}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = sh.extract(buf, prm)
+        for k in stage_keys:
+            acc[k] += getattr(res, k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([int(res.n_points), int(res.n_cells)], dtype=torch.int64, device=device)
+        dist.all_reduce(tot)
+        n_points, n_cells = int(tot[0]), int(tot[1])
+    else:
+        n_points, n_cells = int(res.n_points), int(res.n_cells)
+
+    if rank == 0:
+        voxels = float(n) * n * gnz
+        stages = {k: acc[k] / args.steps for k in stage_keys}
+        alg_bytes = float(n) * n * (sh.hi - sh.lo) * np.dtype(dtype).itemsize     # what one classify launch reads
+        classify_gbs = alg_bytes / (stages["ms_classify"] * 1e-3) / 1e9
+        pass_ms = stages["ms_classify"] + stages["ms_count"] + stages["ms_scan"]
+        out = {
+            "metric": "Mvoxels/s polygonized + achieved HBM GB/s, 1024^3 float32 @1/2/4/8 GPU",
+            "value": round(voxels * args.steps / dt / 1e6, 1),
+            "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == np.float32 else "u8",
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%dx%d %s iso=%g, triangles+projection (thr %g, step 0.25, relax 0.95, max 50)"
+                                   % (args.workload, n, n, gnz, np.dtype(dtype).name, iso, thr),
+                       "per_gpu": "%dx%dx%d slab + %d-slice halo" % (n, n, sh.z1 - sh.z0, 8 if world > 1 else 0),
+                       "parallelism": "zslab%d" % world,
+                       "points": n_points, "cells": n_cells},
+            "roofline": {"bound": "hbm", "kernel": "k_classify_flat (threshold + bit-pack sweep)",
+                         "achieved": round(classify_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(classify_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": alg_bytes,
+                         "classify_count_scan_pass": {"ms": round(pass_ms, 4),
+                                                      "achieved": round(alg_bytes / (pass_ms * 1e-3) / 1e9, 1),
+                                                      "frac": round(alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

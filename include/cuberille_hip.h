@@ -1,0 +1,147 @@
+/*
+ * cuberille_hip.h -- C ABI of the MI355X (gfx950) cuberille iso-surface extractor.
+ *
+ * This is the drop-in boundary of the one accelerated hot path:
+ *   itk::CuberilleImageToMeshFilter<TInputImage,TOutputMesh,TInterpolator>::GenerateData()
+ *   reference: Source/itkCuberilleImageToMeshFilter.txx:59-216 and everything it calls
+ *   (218-332, 439-498; lookup classes Source/itkCuberilleImageToMeshFilter.h:243-313).
+ * The C++ filter template of the same name shipped in
+ * midas-journal-740_amd/itk/itkCuberilleImageToMeshFilter.h marshals its image and
+ * its eight parameters into the structs below inside GenerateData() and fills the
+ * itk::Mesh from the flat buffers that come back.  Plain pointers and sizes only:
+ * no C++ or torch types cross this line.
+ *
+ * Library: midas-journal-740_amd/csrc/libcuberille_hip.so (built by
+ * __graft_entry__.build() / csrc/Makefile with hipcc --offload-arch=gfx950).
+ * There is NO CPU fallback: every entry point that computes returns
+ * CUBERILLE_ERR_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Threading: a context is not thread-safe; distinct contexts are independent.
+ * All work is stream-ordered on the context's stream and complete on return unless
+ * a function says otherwise.
+ */
+#ifndef CUBERILLE_HIP_H
+#define CUBERILLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUBERILLE_ABI_VERSION 1
+
+/* status codes (reference behaviour: the filter has no explicit checks and ITK throws
+ * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
+ * non-zero status into itkExceptionMacro with cuberille_last_error()) */
+enum {
+  CUBERILLE_OK = 0,
+  CUBERILLE_ERR_ARGUMENT = 1,   /* null pointer, bad pixel type, non-positive size or spacing */
+  CUBERILLE_ERR_NO_DEVICE = 2,  /* no usable HIP device / wrong architecture */
+  CUBERILLE_ERR_HIP = 3,        /* a HIP runtime call failed; text in cuberille_last_error */
+  CUBERILLE_ERR_STATE = 4,      /* call order violated (emit before count, ...) */
+  CUBERILLE_ERR_HALO = 5,       /* slab does not carry the halo the owned range needs */
+  CUBERILLE_ERR_LIMIT = 6       /* volume exceeds an implementation limit */
+};
+
+/* InputPixelType of the filter (h:150).  Same numbering as the oracle. */
+enum {
+  CUBERILLE_PIX_U8 = 0, CUBERILLE_PIX_I8 = 1, CUBERILLE_PIX_U16 = 2, CUBERILLE_PIX_I16 = 3,
+  CUBERILLE_PIX_U32 = 4, CUBERILLE_PIX_I32 = 5, CUBERILLE_PIX_F32 = 6, CUBERILLE_PIX_F64 = 7
+};
+
+/* The input image: replaces itk::Image::{GetBufferedRegion, GetSpacing, GetOrigin,
+ * GetDirection, GetBufferPointer} as used at txx:71-99,266-270. */
+typedef struct {
+  int32_t pixel_type;
+  int64_t dims[3];        /* Nx, Ny, Nz of the buffer handed over; x fastest */
+  double spacing[3];
+  double origin[3];
+  double direction[9];    /* row-major direction cosines */
+} cuberille_image_desc;
+
+/* The filter's parameters: h:180-228, constructor defaults txx:33-40. */
+typedef struct {
+  double iso_value;              /* m_IsoSurfaceValue; converted to the pixel type (txx:140) */
+  int32_t generate_triangles;    /* m_GenerateTriangleFaces (default 1) */
+  int32_t project_vertices;      /* m_ProjectVerticesToIsoSurface (default 1) */
+  double distance_threshold;     /* m_ProjectVertexSurfaceDistanceThreshold (0.5) */
+  double step_length;            /* m_ProjectVertexStepLength (-1 => 0.25*max spacing, txx:82-85) */
+  double relaxation;             /* m_ProjectVertexStepLengthRelaxationFactor (0.95) */
+  uint32_t max_steps;            /* m_ProjectVertexMaximumNumberOfSteps (50) */
+  int32_t emulate_empty_slice_aliasing; /* 1: reproduce the two-plane lookup quirk of txx:156-161
+                                           when a slice holds no inside voxel */
+} cuberille_params;
+
+/* Z-slab placement for multi-GPU runs (one process per GPU).
+ * NULL or all-zero means "the buffer is the whole volume". */
+typedef struct {
+  int64_t global_nz;        /* Nz of the whole volume */
+  int64_t z_begin;          /* global z of the buffer's first slice */
+  int64_t own_z0, own_z1;   /* global slices [own_z0, own_z1) this rank emits */
+  uint64_t point_id_offset; /* ids of this rank's first point / first cell; set them */
+  uint64_t cell_id_offset;  /*   with cuberille_emit after the count all-gather */
+} cuberille_slab;
+
+typedef struct {
+  uint64_t n_points;        /* points this call/rank owns */
+  uint64_t n_cells;         /* cells this call/rank owns (quads, or 2 triangles per quad) */
+  int32_t verts_per_cell;   /* 4 or 3 */
+  int32_t reserved;
+  /* device time of each stage in milliseconds (HIP events on the context's stream) */
+  float ms_classify;        /* threshold + bit-pack sweep over the volume */
+  float ms_count;           /* per-word face / created-corner counts */
+  float ms_scan;            /* prefix sums */
+  float ms_emit;            /* points + quads scatter */
+  float ms_project;         /* vertex projection (txx:439-474) */
+  float ms_triangulate;     /* quad split (txx:286-321) */
+  float ms_total;           /* first classify launch .. last kernel done */
+  uint64_t proj_iterations; /* total iterations of the projection loop */
+} cuberille_result;
+
+typedef struct cuberille_ctx cuberille_ctx;
+
+/* library */
+int cuberille_abi_version(void);
+/* number of usable gfx950 devices (0 when there is none; never fails) */
+int cuberille_device_count(void);
+const char *cuberille_last_error(const cuberille_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* context: owns a stream and the device workspace (re-used across calls) */
+int cuberille_create(cuberille_ctx **out, int device_id);
+void cuberille_destroy(cuberille_ctx *ctx);
+/* run on a caller's hipStream_t instead of the context's own (NULL = back to own) */
+int cuberille_set_stream(cuberille_ctx *ctx, void *hip_stream);
+
+/* One call = GenerateData(): upload `host_voxels`, extract, leave the mesh on the device. */
+int cuberille_extract_host(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *host_voxels,
+                           const cuberille_params *prm, cuberille_result *res);
+/* Same with the volume already resident in HBM (`dev_voxels` is a device pointer). */
+int cuberille_extract_device(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
+                             const cuberille_params *prm, const cuberille_slab *slab, cuberille_result *res);
+
+/* The two halves of extract_device, for multi-GPU: count -> (all-gather of counts, prefix on the
+ * host) -> emit with this rank's id offsets. */
+int cuberille_count(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
+                    const cuberille_params *prm, const cuberille_slab *slab,
+                    uint64_t *n_points, uint64_t *n_cells);
+int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, uint64_t cell_id_offset,
+                   cuberille_result *res);
+
+/* Result buffers of the last extract/emit (valid until the next call on this context):
+ * points = float[3*n_points], cells = uint64[verts_per_cell*n_cells] holding GLOBAL point ids. */
+int cuberille_mesh_device(const cuberille_ctx *ctx, const float **d_points, const uint64_t **d_cells);
+int cuberille_mesh_download(cuberille_ctx *ctx, float *points, uint64_t *cells);
+
+/* Introspection used by the parity tests: copy the packed inside-bit volume of the last
+ * count ((Nx+63)/64 uint64 words per x-row, rows in (z,y) raster order) to `words`. */
+int cuberille_debug_bits(cuberille_ctx *ctx, uint64_t *words, size_t n_words);
+/* Per buffer slice: non-zero when the slice holds at least one inside voxel.  The multi-GPU
+ * driver gathers these to detect the empty-slice aliasing quirk (Q1) crossing a slab boundary. */
+int cuberille_slice_occupancy(cuberille_ctx *ctx, uint32_t *occupied, size_t n_slices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,400 @@
+// C-ABI host layer of the MI355X cuberille extractor (include/cuberille_hip.h).
+//
+// Plays the role of the body of itk::CuberilleImageToMeshFilter::GenerateData()
+// (/root/reference/Source/itkCuberilleImageToMeshFilter.txx:59-216): resolves the
+// parameters the way txx:75-95 does, then drives the HIP kernels of
+// cuberille_kernels.hip on one stream.  No CPU fallback exists: without a gfx950
+// device every computing entry point fails with CUBERILLE_ERR_NO_DEVICE.
+
+#include "../../include/cuberille_hip.h"
+#include "cuberille_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace cuberille;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    // grow with head-room so that repeated calls on similar volumes do not re-allocate
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct cuberille_ctx {
+  int device = 0;
+  hipStream_t own = nullptr, stream = nullptr;
+  std::string err;
+  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, quads;
+  Totals *hostTotals = nullptr;          // pinned
+  hipEvent_t ev[8] = {};
+  // state of the last count
+  bool counted = false, haveMesh = false;
+  Grid g{};
+  Geo geo{};
+  Params prm{};
+  int pixel_type = 0;
+  Workspace w{};
+  size_t nwords = 0, nseg = 0;
+  Totals tot{};
+  cuberille_result res{};
+};
+
+namespace {
+
+int fail(cuberille_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((c), CUBERILLE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+bool is_gfx950(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+size_t pixel_size(int pt) {
+  switch (pt) {
+    case CUBERILLE_PIX_U8: case CUBERILLE_PIX_I8: return 1;
+    case CUBERILLE_PIX_U16: case CUBERILLE_PIX_I16: return 2;
+    case CUBERILLE_PIX_U32: case CUBERILLE_PIX_I32: case CUBERILLE_PIX_F32: return 4;
+    case CUBERILLE_PIX_F64: return 8;
+  }
+  return 0;
+}
+
+// 3x3 inverse by cofactors (the parity tests hand the same matrix to the CPU checker, which
+// uses the same formula; for the identity direction of every shipped volume it is exact)
+void invert3(const double m[9], double inv[9]) {
+  const double c00 = m[4] * m[8] - m[5] * m[7];
+  const double c01 = m[5] * m[6] - m[3] * m[8];
+  const double c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  inv[0] = c00 / det;
+  inv[1] = (m[2] * m[7] - m[1] * m[8]) / det;
+  inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+  inv[3] = c01 / det;
+  inv[4] = (m[0] * m[8] - m[2] * m[6]) / det;
+  inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+  inv[6] = c02 / det;
+  inv[7] = (m[1] * m[6] - m[0] * m[7]) / det;
+  inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+}
+
+int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox, const cuberille_params *prm) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!img || !vox || !prm) return fail(c, CUBERILLE_ERR_ARGUMENT, "null image, voxel or parameter pointer");
+  if (pixel_size(img->pixel_type) == 0) return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown pixel type");
+  for (int i = 0; i < 3; i++) {
+    if (img->dims[i] < 1) return fail(c, CUBERILLE_ERR_ARGUMENT, "image dimensions must be >= 1");
+    if (img->dims[i] > 0x7fffffffLL) return fail(c, CUBERILLE_ERR_LIMIT, "image dimension exceeds 2^31-1");
+    if (!(img->spacing[i] > 0.0)) return fail(c, CUBERILLE_ERR_ARGUMENT, "spacing must be > 0");
+  }
+  return CUBERILLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cuberille_abi_version(void) { return CUBERILLE_ABI_VERSION; }
+
+int cuberille_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; d++) if (is_gfx950(d)) ok++;
+  return ok;
+}
+
+const char *cuberille_last_error(const cuberille_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int cuberille_create(cuberille_ctx **out, int device_id) {
+  if (!out) return fail(nullptr, CUBERILLE_ERR_ARGUMENT, "null output pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, CUBERILLE_ERR_NO_DEVICE, "no HIP device: the cuberille hot path has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, CUBERILLE_ERR_ARGUMENT, "device id out of range");
+  if (!is_gfx950(device_id))
+    return fail(nullptr, CUBERILLE_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library carries gfx950 code only");
+  cuberille_ctx *c = new (std::nothrow) cuberille_ctx;
+  if (!c) return fail(nullptr, CUBERILLE_ERR_ARGUMENT, "out of host memory");
+  c->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&c->hostTotals, sizeof(Totals), hipHostMallocDefault);
+  for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+  if (e == hipSuccess) e = c->totals.reserve(sizeof(Totals));
+  if (e != hipSuccess) {
+    g_create_error = std::string("cuberille_create: ") + hipGetErrorString(e);
+    cuberille_destroy(c);
+    return CUBERILLE_ERR_HIP;
+  }
+  c->stream = c->own;
+  *out = c;
+  return CUBERILLE_OK;
+}
+
+void cuberille_destroy(cuberille_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own) (void)hipStreamSynchronize(c->own);
+  DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->occ, &c->alias, &c->prefix, &c->segV, &c->segQ, &c->segBaseV,
+                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->quads};
+  for (DevBuf *b : bufs) b->release();
+  if (c->hostTotals) (void)hipHostFree(c->hostTotals);
+  for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+}
+
+int cuberille_set_stream(cuberille_ctx *c, void *hip_stream) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own;
+  return CUBERILLE_OK;
+}
+
+int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
+                    const cuberille_params *prm, const cuberille_slab *slab, uint64_t *n_points, uint64_t *n_cells) {
+  int rc = validate(c, img, dev_voxels, prm);
+  if (rc) return rc;
+  c->counted = false;
+  c->haveMesh = false;
+  HIP_TRY(c, hipSetDevice(c->device));
+
+  // ---- layout -----------------------------------------------------------------------------
+  Grid g{};
+  g.nx = (int)img->dims[0]; g.ny = (int)img->dims[1]; g.nzb = (int)img->dims[2];
+  g.W = (g.nx + 63) / 64;
+  g.lastpos = (g.nx - 1) & 63;
+  const bool whole = !slab || (slab->global_nz == 0 && slab->z_begin == 0 && slab->own_z0 == 0 && slab->own_z1 == 0);
+  if (whole) {
+    g.gnz = g.nzb; g.zglob0 = 0; g.oz0 = 0; g.oz1 = g.nzb;
+  } else {
+    if (slab->global_nz < 1 || slab->z_begin < 0 || slab->z_begin + g.nzb > slab->global_nz ||
+        slab->own_z0 < slab->z_begin || slab->own_z1 > slab->z_begin + g.nzb || slab->own_z0 >= slab->own_z1)
+      return fail(c, CUBERILLE_ERR_ARGUMENT, "slab ranges are inconsistent with the buffer");
+    // the owned range needs 2 slices below (ids of corners created one slice down depend on the
+    // slice below that) and 1 above, unless the volume ends there
+    const long long needLo = slab->own_z0 >= 2 ? slab->own_z0 - 2 : 0;
+    const long long needHi = slab->own_z1 < slab->global_nz ? slab->own_z1 + 1 : slab->global_nz;
+    if (slab->z_begin > needLo || slab->z_begin + g.nzb < needHi)
+      return fail(c, CUBERILLE_ERR_HALO, "slab buffer must hold 2 halo slices below and 1 above the owned range");
+    g.gnz = slab->global_nz; g.zglob0 = slab->z_begin;
+    g.oz0 = (int)(slab->own_z0 - slab->z_begin);
+    g.oz1 = (int)(slab->own_z1 - slab->z_begin);
+  }
+  g.cz0 = g.oz0 > 0 ? g.oz0 - 1 : 0;
+  const size_t nrowsAll = (size_t)g.ny * g.nzb;
+  const size_t nwordsAll = nrowsAll * g.W;
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const size_t nseg = (nwords + 63) / 64;
+  if (nseg > 0x7fffffffULL) return fail(c, CUBERILLE_ERR_LIMIT, "volume too large for one device scan");
+
+  // ---- geometry and parameters (txx:75-85) ----------------------------------------------------
+  Geo geo{};
+  double maxSpacing = img->spacing[0];
+  for (int i = 0; i < 3; i++) {
+    geo.spacing[i] = img->spacing[i];
+    geo.origin[i] = img->origin[i];
+    geo.gcoef[i] = (float)(0.5 * (1.0 / img->spacing[i]));
+    if (img->spacing[i] > maxSpacing) maxSpacing = img->spacing[i];
+  }
+  for (int i = 0; i < 9; i++) geo.dir[i] = img->direction[i];
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 3; k++) geo.i2p[r * 3 + k] = geo.dir[r * 3 + k] * geo.spacing[k];
+  invert3(geo.i2p, geo.p2i);
+  Params p{};
+  p.iso = prm->iso_value;
+  p.thr = prm->distance_threshold;
+  p.step = prm->step_length < 0.0 ? maxSpacing * 0.25 : prm->step_length;
+  p.relax = prm->relaxation;
+  p.max_steps = prm->max_steps;
+  p.triangles = prm->generate_triangles != 0;
+  p.project = prm->project_vertices != 0;
+  p.q1 = prm->emulate_empty_slice_aliasing != 0;
+
+  // ---- workspace ----------------------------------------------------------------------------------
+  HIP_TRY(c, c->bits.reserve(nwordsAll * sizeof(u64)));
+  HIP_TRY(c, c->occ.reserve((size_t)g.nzb * sizeof(u32)));
+  HIP_TRY(c, c->alias.reserve((size_t)g.nzb * sizeof(int)));
+  HIP_TRY(c, c->prefix.reserve(nwords * sizeof(u32)));
+  HIP_TRY(c, c->segV.reserve(nseg * sizeof(u64)));
+  HIP_TRY(c, c->segQ.reserve(nseg * sizeof(u64)));
+  HIP_TRY(c, c->segBaseV.reserve(nseg * sizeof(u64)));
+  HIP_TRY(c, c->segBaseQ.reserve(nseg * sizeof(u64)));
+  const size_t tempBytes = scan_temp_bytes(nseg);
+  HIP_TRY(c, c->scanTemp.reserve(tempBytes));
+  Workspace w{};
+  w.vox = dev_voxels;
+  w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)c->occ.p; w.alias = (int *)c->alias.p;
+  w.prefix = (u32 *)c->prefix.p;
+  w.segV = (u64 *)c->segV.p; w.segQ = (u64 *)c->segQ.p;
+  w.segBaseV = (u64 *)c->segBaseV.p; w.segBaseQ = (u64 *)c->segBaseQ.p;
+  w.totals = (Totals *)c->totals.p;
+
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemsetAsync(w.sliceOcc, 0, (size_t)g.nzb * sizeof(u32), s));
+  HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals), s));
+  HIP_TRY(c, hipEventRecord(c->ev[0], s));
+  HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, s));
+  HIP_TRY(c, hipEventRecord(c->ev[1], s));
+  HIP_TRY(c, launch_alias(w, g, p.q1, s));
+  HIP_TRY(c, launch_count(w, g, nwords, s));
+  HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  HIP_TRY(c, launch_scan(c->scanTemp.p, tempBytes, w.segV, w.segBaseV, nseg, s));
+  HIP_TRY(c, launch_scan(c->scanTemp.p, tempBytes, w.segQ, w.segBaseQ, nseg, s));
+  HIP_TRY(c, launch_finalize(w, g, nwords, s));
+  HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->tot = *c->hostTotals;
+  if (c->tot.err & ERRF_ALIAS_UNKNOWN)
+    return fail(c, CUBERILLE_ERR_HALO,
+                "an empty slice makes the reference re-use vertices created below this slab's halo (DESIGN.md Q1)");
+
+  c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
+  c->nwords = nwords; c->nseg = nseg;
+  c->counted = true;
+  std::memset(&c->res, 0, sizeof(c->res));
+  c->res.n_points = c->tot.totV - c->tot.V0;
+  c->res.n_cells = (c->tot.totQ - c->tot.Q0) * (p.triangles ? 2 : 1);
+  c->res.verts_per_cell = p.triangles ? 3 : 4;
+  if (n_points) *n_points = c->res.n_points;
+  if (n_cells) *n_cells = c->res.n_cells;
+  return CUBERILLE_OK;
+}
+
+int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit called before a successful cuberille_count");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const u64 nV = c->tot.totV;                 // ghost + owned
+  const u64 nGhost = c->tot.V0;
+  const u64 nQ = c->tot.totQ - c->tot.Q0;
+  HIP_TRY(c, c->points.reserve((size_t)(nV ? nV : 1) * 3 * sizeof(float)));
+  HIP_TRY(c, c->cells.reserve((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
+  if (c->prm.triangles) HIP_TRY(c, c->quads.reserve((size_t)(nQ ? nQ : 1) * 4 * sizeof(u64)));
+  Workspace &w = c->w;
+  w.points = (float *)c->points.p;
+  w.cells = (u64 *)c->cells.p;
+  w.quads = (u64 *)c->quads.p;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipEventRecord(c->ev[4], s));
+  HIP_TRY(c, launch_emit(w, c->g, c->geo, c->prm.triangles, point_id_offset, cell_id_offset, s));
+  HIP_TRY(c, hipEventRecord(c->ev[5], s));
+  if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));
+  HIP_TRY(c, hipEventRecord(c->ev[6], s));
+  if (c->prm.triangles) HIP_TRY(c, launch_triangulate(w, nQ, point_id_offset, nGhost, s));
+  HIP_TRY(c, hipEventRecord(c->ev[7], s));
+  HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->tot.iters = c->hostTotals->iters;
+  cuberille_result &r = c->res;
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_scan, c->ev[2], c->ev[3]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit, c->ev[4], c->ev[5]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_triangulate, c->ev[6], c->ev[7]));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[3]));
+  HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
+  r.ms_total = a + b;                        // device time; excludes the host gap between count and emit
+  r.proj_iterations = c->tot.iters;
+  c->haveMesh = true;
+  c->counted = false;                        // the workspace now belongs to this mesh
+  if (res) *res = r;
+  return CUBERILLE_OK;
+}
+
+int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
+                             const cuberille_params *prm, const cuberille_slab *slab, cuberille_result *res) {
+  uint64_t np = 0, nc = 0;
+  int rc = cuberille_count(c, img, dev_voxels, prm, slab, &np, &nc);
+  if (rc) return rc;
+  return cuberille_emit(c, slab ? slab->point_id_offset : 0, slab ? slab->cell_id_offset : 0, res);
+}
+
+int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, const void *host_voxels,
+                           const cuberille_params *prm, cuberille_result *res) {
+  int rc = validate(c, img, host_voxels, prm);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)img->dims[0] * img->dims[1] * img->dims[2] * pixel_size(img->pixel_type);
+  HIP_TRY(c, c->voxOwn.reserve(bytes));
+  HIP_TRY(c, hipMemcpyAsync(c->voxOwn.p, host_voxels, bytes, hipMemcpyHostToDevice, c->stream));
+  return cuberille_extract_device(c, img, c->voxOwn.p, prm, nullptr, res);
+}
+
+int cuberille_mesh_device(const cuberille_ctx *c, const float **d_points, const uint64_t **d_cells) {
+  if (!c || !c->haveMesh) return CUBERILLE_ERR_STATE;
+  if (d_points) *d_points = (const float *)c->points.p + 3 * c->tot.V0;
+  if (d_cells) *d_cells = (const uint64_t *)c->cells.p;
+  return CUBERILLE_OK;
+}
+
+int cuberille_mesh_download(cuberille_ctx *c, float *points, uint64_t *cells) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const cuberille_result &r = c->res;
+  if (points && r.n_points)
+    HIP_TRY(c, hipMemcpyAsync(points, (const float *)c->points.p + 3 * c->tot.V0, r.n_points * 3 * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+  if (cells && r.n_cells)
+    HIP_TRY(c, hipMemcpyAsync(cells, c->cells.p, r.n_cells * r.verts_per_cell * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CUBERILLE_OK;
+}
+
+int cuberille_debug_bits(cuberille_ctx *c, uint64_t *words, size_t n_words) {
+  if (!c || !words) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no classified volume on this context");
+  const size_t have = (size_t)c->g.ny * c->g.nzb * c->g.W;
+  if (n_words > have) return fail(c, CUBERILLE_ERR_ARGUMENT, "more words requested than the bit volume holds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(words, c->bits.p, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CUBERILLE_OK;
+}
+
+int cuberille_slice_occupancy(cuberille_ctx *c, uint32_t *occupied, size_t n_slices) {
+  if (!c || !occupied) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no classified volume on this context");
+  if (n_slices > (size_t)c->g.nzb) return fail(c, CUBERILLE_ERR_ARGUMENT, "more slices requested than the buffer holds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(occupied, c->occ.p, n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CUBERILLE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,756 @@
+// HIP kernels of the cuberille hot path for gfx950 (MI355X, 64-lane wavefronts).
+//
+// Reference being re-implemented (not translated):
+//   /root/reference/Source/itkCuberilleImageToMeshFilter.txx:136-206 (sweep),
+//   256-332 (AddVertex/AddQuadFace), 439-474 (projection), 478-498 (gradient).
+//
+// Design: the order-dependent raster sweep with its two
+// std::map lookups is replaced by a closed form over a packed inside-bit volume:
+//   classify : one coalesced pass over the voxels, 16 B per lane, thresholds against
+//              the iso value and packs 64 voxels per uint64 word (wave ballot /
+//              cross-lane OR)                                        -> bits
+//   count    : one lane per 64-voxel word, SWAR boolean algebra over the 27
+//              neighbour bit-rows gives the 6 face masks and the 8 "this voxel
+//              creates corner i" masks; popcounts + a wavefront scan give the
+//              in-segment exclusive prefix                           -> prefix, seg totals
+//   scan     : hipCUB exclusive sum over the per-segment totals      -> segBase
+//   emit     : points and quads written at their final, reference-order indices
+//   project  : one lane per vertex, the damped gradient walk with the gradient
+//              image evaluated on the fly (never materialised)
+//   triangulate : shorter-diagonal split on the projected coordinates.
+// Bit-exactness of the floating-point part against the CPU oracle relies on
+// -ffp-contract=off (no FMA fusion) and IEEE f64 div/sqrt; see csrc/Makefile.
+
+#include "cuberille_internal.h"
+#include "../../include/cuberille_hip.h"
+
+#include <hipcub/hipcub.hpp>
+#include <type_traits>
+#include <utility>
+
+namespace cuberille {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ u64 lowmask(int b) { return (1ull << b) - 1ull; }   // b in 0..63
+__device__ __forceinline__ int popc64(u64 v) { return __popcll(v); }
+
+// corner number i (txx:244-251) -> block position code e = x | y<<1 | z<<2, and back
+__device__ __constant__ const int kCornerEnc[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+__device__ __constant__ const int kEncCorner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+// face -> its four corners in the order of txx:197-202
+__device__ __constant__ const int kFaceCorner[6][4] = {{0, 4, 7, 3}, {0, 1, 5, 4}, {1, 2, 6, 5},
+                                                       {2, 3, 7, 6}, {0, 3, 2, 1}, {4, 5, 6, 7}};
+// face -> 8-bit mask of its corners (txx:226-231)
+__device__ __constant__ const unsigned kFaceCornerMask[6] = {0x99, 0x33, 0x66, 0xCC, 0x0F, 0xF0};
+
+// ---------------------------------------------------------------------------------------------
+// K1: classify (threshold + bit-pack).  inside(u) := !(pixel(u) < iso)   (txx:139-141,167)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  union { uint4 raw; T v[N]; };
+};
+
+// Fast path: nx % 64 == 0, so the volume is a flat array of 64-voxel words.  Each lane
+// loads 16 B (VPL voxels), builds VPL bits; LPW = 64/VPL adjacent lanes OR their partial
+// words together.  One wave turns U KiB of voxels into U*VPL words per trip.
+template <class T, int U>
+__global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox, u64 *__restrict__ bits,
+                                                       u64 nchunks, double isoD, u32 *__restrict__ sliceOcc,
+                                                       u64 wordsPerSlice) {
+  constexpr int VPL = 16 / sizeof(T);
+  constexpr int LPW = 64 / VPL;
+  const T iso = (T)isoD;
+  const int lane = threadIdx.x & 63;
+  const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+  const int sub = lane % LPW;                 // position of this lane inside its word
+  for (u64 c = wave * U; c < nchunks; c += nwaves * U) {
+    Vec16<T> r[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (c + u < nchunks)
+        r[u].raw = *reinterpret_cast<const uint4 *>(vox + ((c + u) * 64 + lane) * VPL);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (c + u >= nchunks) break;            // wave-uniform
+      u32 m = 0;
+#pragma unroll
+      for (int j = 0; j < VPL; j++) m |= (!(r[u].v[j] < iso) ? 1u : 0u) << j;
+      u64 part = (u64)m << (sub * VPL);
+#pragma unroll
+      for (int s = 1; s < LPW; s <<= 1) part |= __shfl_xor(part, s, 64);
+      if (sub == 0) {
+        const u64 widx = (c + u) * VPL + lane / LPW;
+        bits[widx] = part;
+        if (part) sliceOcc[widx / wordsPerSlice] = 1u;   // benign race: every writer stores 1
+      }
+    }
+  }
+}
+
+// Generic path (any nx): one wave per (row, word); lane l tests voxel x = 64k + l; the
+// wave ballot IS the packed word.
+template <class T>
+__global__ __launch_bounds__(256) void k_classify_rows(const T *__restrict__ vox, u64 *__restrict__ bits,
+                                                       int nx, int W, u64 t0, u64 nrows, u64 rowsPerSlice, double isoD,
+                                                       u32 *__restrict__ sliceOcc) {
+  const T iso = (T)isoD;
+  const int lane = threadIdx.x & 63;
+  const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+  const u64 total = nrows * (u64)W;
+  for (u64 t = t0 + wave; t < total; t += nwaves) {
+    const u64 row = t / W;
+    const int k = (int)(t % W);
+    const int x = k * 64 + lane;
+    bool in = false;
+    if (x < nx) in = !(vox[row * (u64)nx + x] < iso);
+    const u64 word = __ballot(in);
+    if (lane == 0) {
+      bits[t] = word;
+      if (word) sliceOcc[row / rowsPerSlice] = 1u;
+    }
+  }
+}
+
+// Empty-slice aliasing table (reference quirk Q1, txx:139-141 precede 156-161: the lookup
+// planes are swapped only when an INSIDE voxel is met at a new z).  alias[z] = zp when
+// slice z is occupied, slice z-1 is not, and zp < z-1 is the previous occupied slice:
+// bottom-plane corners of slice z are then looked up among the top-plane corners of zp.
+__global__ void k_alias(const u32 *__restrict__ sliceOcc, int *__restrict__ alias, Grid g, int q1,
+                        Totals *__restrict__ tot) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int prev = -1;
+  for (int z = 0; z < g.nzb; z++) {
+    int a = -1;
+    if (sliceOcc[z]) {
+      // (a slab cannot see occupied slices below its buffer: the multi-GPU driver checks the
+      //  gathered per-slice occupancy for that case)
+      if (q1 && z > 0 && !sliceOcc[z - 1] && prev >= 0) a = prev;
+      prev = z;
+    }
+    // the aliased source rows must lie inside the counted range to have ids
+    if (a >= 0 && a < g.cz0 && z >= g.cz0) { atomicOr(&tot->err, (u32)ERRF_ALIAS_UNKNOWN); a = -1; }
+    alias[z] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Word classification: everything a 64-voxel word needs, from the 27 neighbour bit-rows.
+// ---------------------------------------------------------------------------------------------
+struct Rows3 { u64 m, c, p; };   // bit x = inside(x-1), inside(x), inside(x+1), border-clamped (I2)
+
+__device__ __forceinline__ Rows3 load_row(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k) {
+  const u64 *r = bits + ((size_t)z * g.ny + y) * g.W;
+  Rows3 o;
+  o.c = r[k];
+  const u64 prevb = (k > 0) ? (r[k - 1] >> 63) : (o.c & 1ull);
+  o.m = (o.c << 1) | prevb;
+  if (k < g.W - 1) o.p = (o.c >> 1) | (r[k + 1] << 63);
+  else o.p = (o.c >> 1) | (o.c & (1ull << g.lastpos));
+  return o;
+}
+
+__device__ __forceinline__ u64 valid_mask(const Grid &g, int k) {
+  return (k == g.W - 1 && g.lastpos != 63) ? ((2ull << g.lastpos) - 1ull) : ~0ull;
+}
+
+struct WordInfo {
+  u64 F[6];   // F[f] bit x: voxel x emits a quad on face f                  (txx:164-173)
+  u64 C[8];   // C[i] bit x: voxel x is the first to need its corner i, i.e. the reference
+              //             would call AddVertex for it here                 (txx:179-194)
+};
+
+struct Neigh {
+  Rows3 v[3][3];     // [dz+1][dy+1]
+  u64 exX[3];        // voxel x+dx exists (dx = -1,0,+1)
+  u64 exY[3], exZ[3];
+};
+
+template <int SX>
+__device__ __forceinline__ u64 selx(const Rows3 &r) { return SX < 0 ? r.m : (SX == 0 ? r.c : r.p); }
+
+// inside-bit of block member e (code x|y<<1|z<<2) of the 2x2x2 block around corner D of voxel x
+template <int D, int E>
+__device__ __forceinline__ u64 blk(const Neigh &n) {
+  constexpr int sx = (D & 1) - (E & 1), sy = ((D >> 1) & 1) - ((E >> 1) & 1), sz = (D >> 2) - (E >> 2);
+  return selx<sx>(n.v[sz + 1][sy + 1]);
+}
+// block member e activates the corner: it exists, is inside, and at least one of its three
+// face neighbours inside the block is outside
+template <int D, int E>
+__device__ __forceinline__ u64 act(const Neigh &n) {
+  constexpr int sx = (D & 1) - (E & 1), sy = ((D >> 1) & 1) - ((E >> 1) & 1), sz = (D >> 2) - (E >> 2);
+  const u64 ex = n.exX[sx + 1] & n.exY[sy + 1] & n.exZ[sz + 1];
+  return ex & blk<D, E>(n) & ~(blk<D, E ^ 1>(n) & blk<D, E ^ 2>(n) & blk<D, E ^ 4>(n));
+}
+template <int D, int... Es>
+__device__ __forceinline__ u64 act_any_later(const Neigh &n, std::integer_sequence<int, Es...>) {
+  // members with code > D come earlier in raster order (they have smaller coordinates)
+  return (0ull | ... | act<D, D + 1 + Es>(n));
+}
+template <int I>
+__device__ __forceinline__ u64 created(const Neigh &n) {
+  constexpr int D = (I == 2) ? 3 : (I == 3) ? 2 : (I == 6) ? 7 : (I == 7) ? 6 : I;
+  return act<D, D>(n) & ~act_any_later<D>(n, std::make_integer_sequence<int, 7 - D>());
+}
+
+__device__ __forceinline__ void load_neigh(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, Neigh &n) {
+#pragma unroll
+  for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+      n.v[dz + 1][dy + 1] = load_row(bits, g, clampi(y + dy, 0, g.ny - 1), clampi(z + dz, 0, g.nzb - 1), k);
+  const u64 valid = valid_mask(g, k);
+  n.exX[0] = (k == 0) ? ~1ull : ~0ull;
+  n.exX[1] = valid;
+  n.exX[2] = (k == g.W - 1) ? (valid >> 1) : ~0ull;
+  n.exY[0] = (y > 0) ? ~0ull : 0ull;  n.exY[1] = ~0ull;  n.exY[2] = (y < g.ny - 1) ? ~0ull : 0ull;
+  n.exZ[0] = (z > 0) ? ~0ull : 0ull;  n.exZ[1] = ~0ull;  n.exZ[2] = (z < g.nzb - 1) ? ~0ull : 0ull;
+}
+
+// AE[i] (i = 0..3) bit x: bottom corner i of voxel x already exists as a top-plane corner of the
+// aliased source slice zp (any existing inside voxel of slice zp touching that (x,y) corner).
+__device__ __forceinline__ void alias_exists(const u64 *__restrict__ bits, const Grid &g, const Neigh &n,
+                                             int y, int zp, int k, u64 AE[4]) {
+  Rows3 r[3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++) r[dy + 1] = load_row(bits, g, clampi(y + dy, 0, g.ny - 1), zp, k);
+  // corner offsets (dx,dy) of corners 0..3: (0,0) (1,0) (1,1) (0,1); voxels (x+dx-ex, y+dy-ey)
+  auto at = [&](int sx, int sy) -> u64 {
+    const Rows3 &rr = r[sy + 1];
+    const u64 b = sx < 0 ? rr.m : (sx == 0 ? rr.c : rr.p);
+    return b & n.exX[sx + 1] & n.exY[sy + 1];
+  };
+  AE[0] = at(0, 0) | at(-1, 0) | at(0, -1) | at(-1, -1);
+  AE[1] = at(1, 0) | at(0, 0) | at(1, -1) | at(0, -1);
+  AE[2] = at(1, 1) | at(0, 1) | at(1, 0) | at(0, 0);
+  AE[3] = at(0, 1) | at(-1, 1) | at(0, 0) | at(-1, 0);
+}
+
+__device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, const int *__restrict__ alias,
+                                              const Grid &g, int y, int z, int k, WordInfo &w) {
+  Neigh n;
+  load_neigh(bits, g, y, z, k, n);
+  const u64 I = n.v[1][1].c;
+  w.F[0] = I & ~n.v[1][1].m;   // -x   (offsets of txx:122-127)
+  w.F[1] = I & ~n.v[1][0].c;   // -y
+  w.F[2] = I & ~n.v[1][1].p;   // +x
+  w.F[3] = I & ~n.v[1][2].c;   // +y
+  w.F[4] = I & ~n.v[0][1].c;   // -z
+  w.F[5] = I & ~n.v[2][1].c;   // +z
+  w.C[0] = created<0>(n); w.C[1] = created<1>(n); w.C[2] = created<2>(n); w.C[3] = created<3>(n);
+  w.C[4] = created<4>(n); w.C[5] = created<5>(n); w.C[6] = created<6>(n); w.C[7] = created<7>(n);
+  const int zp = alias[z];
+  if (zp >= 0) {
+    u64 AE[4];
+    alias_exists(bits, g, n, y, zp, k, AE);
+#pragma unroll
+    for (int i = 0; i < 4; i++) w.C[i] &= ~AE[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: count.  One lane per word, one wave per 64-word segment of the flat raster order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const int *__restrict__ alias, Grid g,
+                                               size_t nwords, u32 *__restrict__ prefix, u64 *__restrict__ segV,
+                                               u64 *__restrict__ segQ) {
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  u32 packed = 0;
+  if (gi < nwords) {
+    const size_t row = gi / g.W;
+    const int k = (int)(gi % g.W);
+    const int y = (int)(row % g.ny);
+    const int z = g.cz0 + (int)(row / g.ny);
+    WordInfo w;
+    classify_word(bits, alias, g, y, z, k, w);
+    int nV = 0, nQ = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) nV += popc64(w.C[i]);
+#pragma unroll
+    for (int f = 0; f < 6; f++) nQ += popc64(w.F[f]);
+    packed = (u32)nV | ((u32)nQ << 16);   // <= 512 and <= 384 per word: the packed scan cannot carry
+  }
+  u32 incl = packed;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const u32 t = __shfl_up(incl, s, 64);
+    if (lane >= s) incl += t;
+  }
+  if (gi < nwords) prefix[gi] = incl - packed;
+  if (lane == 63 && (gi & ~(size_t)63) < nwords) {
+    segV[gi >> 6] = incl & 0xffffu;
+    segQ[gi >> 6] = incl >> 16;
+  }
+}
+
+__global__ void k_finalize(const u32 *__restrict__ prefix, const u64 *__restrict__ segV, const u64 *__restrict__ segQ,
+                           const u64 *__restrict__ segBaseV, const u64 *__restrict__ segBaseQ, Grid g, size_t nwords,
+                           Totals *__restrict__ tot) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const size_t nseg = (nwords + 63) >> 6;
+  tot->totV = segBaseV[nseg - 1] + segV[nseg - 1];
+  tot->totQ = segBaseQ[nseg - 1] + segQ[nseg - 1];
+  const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
+  if (g0 > 0) {
+    tot->V0 = segBaseV[g0 >> 6] + (prefix[g0] & 0xffffu);
+    tot->Q0 = segBaseQ[g0 >> 6] + (prefix[g0] >> 16);
+  } else {
+    tot->V0 = 0;
+    tot->Q0 = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: emit.
+// ---------------------------------------------------------------------------------------------
+struct EmitArgs {
+  const u64 *bits;
+  const int *alias;
+  const u32 *prefix;
+  const u64 *segBaseV, *segBaseQ;
+  const Totals *tot;
+  float *points;
+  u64 *cells;          // quads (4 ids) -- final cells, or the quad staging buffer when triangulating
+  u64 pointOffset;     // global id of this rank's first point
+};
+
+__device__ __forceinline__ size_t word_index(const Grid &g, int y, int z, int k) {
+  return ((size_t)(z - g.cz0) * g.ny + y) * g.W + k;
+}
+__device__ __forceinline__ int getbit(const u64 *__restrict__ bits, const Grid &g, int x, int y, int z) {
+  return (int)((bits[((size_t)z * g.ny + y) * g.W + (x >> 6)] >> (x & 63)) & 1ull);
+}
+
+// I3 + txx:268-270: lattice corner -> physical point - spacing/2, in the mesh's float coordinates
+__device__ __forceinline__ void corner_point(const Geo &geo, long long cx, long long cy, long long cz, float p[3]) {
+  const double idx[3] = {(double)cx, (double)cy, (double)cz};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) sum += geo.i2p[r * 3 + c] * idx[c];
+    const float v = (float)(sum + geo.origin[r]);
+    p[r] = (float)((double)v - (geo.spacing[r] / 2.0));
+  }
+}
+
+// Global id of lattice corner (cx,cy,cz) (cz local) by the closed form: creator = first block
+// member in raster order that activates it; id = creator's word base + created corners before the
+// creator inside its word + rank of the corner among the creator's created corners.
+__device__ u64 corner_id_generic(const EmitArgs &a, const Grid &g, int cx, int cy, int cz) {
+  int b[8];
+  bool ex[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int x = cx - (e & 1), y = cy - ((e >> 1) & 1), z = cz - (e >> 2);
+    ex[e] = (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nzb);
+    b[e] = getbit(a.bits, g, clampi(x, 0, g.nx - 1), clampi(y, 0, g.ny - 1), clampi(z, 0, g.nzb - 1));
+  }
+  int creator = -1;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const bool ac = ex[e] && b[e] && !(b[e ^ 1] && b[e ^ 2] && b[e ^ 4]);
+    if (ac) creator = e;     // keep the largest code = earliest in raster order
+  }
+  if (creator < 0) return ~0ull;    // not a mesh vertex (cannot happen for a corner of an emitted quad)
+  const int wx = cx - (creator & 1), wy = cy - ((creator >> 1) & 1), wz = cz - (creator >> 2);
+  const int k = wx >> 6, bx = wx & 63;
+  WordInfo w;
+  classify_word(a.bits, a.alias, g, wy, wz, k, w);
+  const size_t gi = word_index(g, wy, wz, k);
+  u64 id = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);
+  unsigned cm = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    id += popc64(w.C[i] & lowmask(bx));
+    cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
+  }
+  const int j = kEncCorner[creator];
+  id += __popc(cm & ((1u << j) - 1u));
+  return id;
+}
+
+// v0 emit: one lane per word, serial over the word's surface voxels.  Correct for every case
+// (including the empty-slice aliasing); the LDS-tiled kernel replaces it on the fast path.
+// Words of the counted slice below the owned range (a slab's ghost slice) only write their points:
+// the rank above needs those coordinates for the triangle split of its first slice.
+__global__ __launch_bounds__(256) void k_emit_words(EmitArgs a, Grid g, Geo geo, size_t nwordsCounted) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nwordsCounted) return;
+  const size_t row = t / g.W;
+  const int k = (int)(t % g.W);
+  const int y = (int)(row % g.ny);
+  const int z = g.cz0 + (int)(row / g.ny);
+  const bool owned = z >= g.oz0;
+  WordInfo w;
+  classify_word(a.bits, a.alias, g, y, z, k, w);
+  u64 active = w.F[0] | w.F[1] | w.F[2] | w.F[3] | w.F[4] | w.F[5];
+  if (!active) return;
+  const size_t gi = t;
+  // ids are global: subtract what was counted below the owned range, add this rank's offset
+  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
+  const u64 baseV = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);
+  const u64 baseQ = a.segBaseQ[gi >> 6] + (a.prefix[gi] >> 16);
+  const int zp = a.alias[z];
+  while (active) {
+    const int bx = __ffsll((long long)active) - 1;
+    active &= active - 1;
+    const int x = k * 64 + bx;
+    unsigned cm = 0, fm = 0;
+    u64 first = baseV;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      first += popc64(w.C[i] & lowmask(bx));
+      cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
+    }
+    u64 q = baseQ;
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+      q += popc64(w.F[f] & lowmask(bx));
+      fm |= (unsigned)((w.F[f] >> bx) & 1ull) << f;
+    }
+    unsigned need = 0;
+#pragma unroll
+    for (int f = 0; f < 6; f++) if (fm & (1u << f)) need |= kFaceCornerMask[f];
+    if (!owned) { need &= cm; fm = 0; }
+    u64 vid[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      vid[i] = 0;
+      if (!(need & (1u << i))) continue;
+      const int cx = x + (kCornerEnc[i] & 1), cy = y + ((kCornerEnc[i] >> 1) & 1), cz = z + (kCornerEnc[i] >> 2);
+      if (cm & (1u << i)) {
+        const u64 lid = first + __popc(cm & ((1u << i) - 1u));    // index in the counted range
+        vid[i] = lid - V0 + a.pointOffset;
+        float p[3];
+        corner_point(geo, cx, cy, g.zglob0 + cz, p);
+        float *dst = a.points + 3 * lid;     // ghost points first, owned points from 3*V0 on
+        dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+      } else {
+        int lz = cz;
+        if (i < 4 && zp >= 0) {
+          // bottom corner on an aliased slice: does the (x,y) key exist among zp's top corners?
+          bool hit = false;
+          for (int e = 0; e < 4; e++) {
+            const int vx = cx - (e & 1), vy = cy - (e >> 1);
+            if (vx >= 0 && vx < g.nx && vy >= 0 && vy < g.ny && getbit(a.bits, g, vx, vy, zp)) hit = true;
+          }
+          if (hit) lz = zp + 1;
+        }
+        vid[i] = corner_id_generic(a, g, cx, cy, lz) - V0 + a.pointOffset;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+      if (!(fm & (1u << f))) continue;
+      u64 *dst = a.cells + 4 * (q - Q0);
+      dst[0] = vid[kFaceCorner[f][0]]; dst[1] = vid[kFaceCorner[f][1]];
+      dst[2] = vid[kFaceCorner[f][2]]; dst[3] = vid[kFaceCorner[f][3]];
+      q++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: projection (txx:439-474) with the gradient image (txx:478-498) evaluated on the fly.
+// Every arithmetic step mirrors the ITK 3.x contract I3..I9 in the same
+// operation order as the oracle, so the float coordinates come out bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Sampler {
+  const T *vox;
+  int nx, ny, nzb;
+  long long zglob0, gnz;
+  __device__ __forceinline__ T at(long long x, long long y, long long zg) const {   // global z in, clamped
+    long long z = zg - zglob0;
+    z = z < 0 ? 0 : (z > nzb - 1 ? nzb - 1 : z);
+    return vox[((size_t)z * ny + y) * nx + x];
+  }
+  __device__ __forceinline__ T at_clamped(long long x, long long y, long long zg) const {
+    x = x < 0 ? 0 : (x > nx - 1 ? nx - 1 : x);
+    y = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    zg = zg < 0 ? 0 : (zg > gnz - 1 ? gnz - 1 : zg);
+    return at(x, y, zg);
+  }
+};
+
+__device__ __forceinline__ long long to_index_clamped(double b, long long end) {
+  if (!(b >= 0.0)) return 0;            // also NaN (quirk Q4): never read out of bounds
+  if (b >= (double)end) return end;
+  return (long long)b;
+}
+
+struct Cell8 {
+  long long lo[3], hi[3];
+  double d[3];
+};
+
+__device__ __forceinline__ void make_cell(const Geo &geo, const long long n[3], const double p[3], Cell8 &c) {
+  double cv[3], ci[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) cv[k] = p[k] - geo.origin[k];                // I4
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) sum += geo.p2i[r * 3 + k] * cv[k];
+    ci[r] = sum;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double b = floor(ci[k]);
+    c.d[k] = ci[k] - b;
+    c.lo[k] = to_index_clamped(b, n[k] - 1);
+    c.hi[k] = to_index_clamped(b + 1.0, n[k] - 1);
+  }
+}
+
+// I6: GradientImageFilter at one pixel
+template <class T>
+__device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo, long long x, long long y, long long z,
+                                            float out[3]) {
+  float local[3];
+  const float f0 = (float)s.at(x, y, z);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float c = geo.gcoef[a];
+    const long long dx = (a == 0), dy = (a == 1), dz = (a == 2);
+    const float fm = (float)s.at_clamped(x - dx, y - dy, z - dz);
+    const float fp = (float)s.at_clamped(x + dx, y + dy, z + dz);
+    float sum = 0.0f;
+    sum += (-c) * fm;
+    sum += 0.0f * f0;
+    sum += c * fp;
+    local[a] = sum;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) sum = (float)((double)sum + geo.dir[r * 3 + c] * (double)local[c]);
+    out[r] = sum;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm,
+                                                 float *__restrict__ points, u64 nPoints, u64 nGhost,
+                                                 Totals *__restrict__ tot) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned myIters = 0;
+  if (v < nPoints) {
+    Sampler<T> s{vox, g.nx, g.ny, g.nzb, g.zglob0, g.gnz};
+    const long long n[3] = {g.nx, g.ny, g.gnz};
+    const double iso = (double)(T)prm.iso;
+    float vertex[3] = {points[3 * v], points[3 * v + 1], points[3 * v + 2]};
+    bool done = false;
+    double step = prm.step;
+    unsigned numberOfSteps = 0;
+    while (!done) {
+      myIters++;
+      const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+      Cell8 c;
+      make_cell(geo, n, p, c);
+      // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights
+      double acc[3] = {0.0, 0.0, 0.0}, value = 0.0, total = 0.0;
+#pragma unroll
+      for (unsigned counter = 0; counter < 8; counter++) {
+        double overlap = 1.0;
+        long long ni[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          if (counter & (1u << k)) { ni[k] = c.hi[k]; overlap *= c.d[k]; }
+          else                     { ni[k] = c.lo[k]; overlap *= 1.0 - c.d[k]; }
+        }
+        if (overlap != 0.0 && total != 1.0) {     // "if (overlap)" + "break once total == 1"
+          float gp[3];
+          gradient_at(s, geo, ni[0], ni[1], ni[2], gp);
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[k] += overlap * (double)gp[k];
+          value += overlap * (double)s.at(ni[0], ni[1], ni[2]);
+          total += overlap;
+        }
+      }
+      float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
+      double sq = 0.0;                                                        // I8 (txx:452)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
+      const double norm = sqrt(sq);
+#pragma unroll
+      for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+      done |= fabs(value - iso) < prm.thr;                                    // txx:456
+      if (done) break;
+      const double sign = (value < iso) ? +1.0 : -1.0;                        // txx:463
+#pragma unroll
+      for (int k = 0; k < 3; k++)                                             // txx:464-467 (I9)
+        vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
+      step *= prm.relax;                                                      // txx:468
+      done |= numberOfSteps++ > prm.max_steps;                                // txx:469
+    }
+    points[3 * v] = vertex[0]; points[3 * v + 1] = vertex[1]; points[3 * v + 2] = vertex[2];
+    if (v < nGhost) myIters = 0;
+  }
+  // one atomic per wave for the iteration statistic
+  unsigned sum = myIters;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
+  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: triangulate (txx:286-321): split along the shorter diagonal of the projected quad.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_triangulate(const u64 *__restrict__ quads, const float *__restrict__ points,
+                                                     u64 *__restrict__ tris, u64 nQuads, u64 pointOffset,
+                                                     u64 nGhost) {
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nQuads) return;
+  u64 f[4];
+  float v[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f[i] = quads[4 * q + i];
+    const float *p = points + 3 * (f[i] - pointOffset + nGhost);   // ghost ids are offset-ghost..offset-1
+    v[i][0] = p[0]; v[i][1] = p[1]; v[i][2] = p[2];
+  }
+  double d02 = 0.0, d13 = 0.0;                                                // I10
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const double d = (double)v[2][k] - (double)v[0][k]; d02 += d * d; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const double d = (double)v[3][k] - (double)v[1][k]; d13 += d * d; }
+  u64 *o = tris + 6 * q;
+  if (d02 >= d13) {                                                           // txx:298-302
+    o[0] = f[0]; o[1] = f[1]; o[2] = f[3];
+    o[3] = f[1]; o[4] = f[2]; o[5] = f[3];
+  } else {                                                                    // txx:303-307
+    o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
+    o[3] = f[0]; o[4] = f[2]; o[5] = f[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <class F>
+static hipError_t by_pixel_type(int pt, F &&fn) {
+  switch (pt) {
+    case CUBERILLE_PIX_U8:  return fn((const uint8_t *)nullptr);
+    case CUBERILLE_PIX_I8:  return fn((const int8_t *)nullptr);
+    case CUBERILLE_PIX_U16: return fn((const uint16_t *)nullptr);
+    case CUBERILLE_PIX_I16: return fn((const int16_t *)nullptr);
+    case CUBERILLE_PIX_U32: return fn((const uint32_t *)nullptr);
+    case CUBERILLE_PIX_I32: return fn((const int32_t *)nullptr);
+    case CUBERILLE_PIX_F32: return fn((const float *)nullptr);
+    case CUBERILLE_PIX_F64: return fn((const double *)nullptr);
+  }
+  return hipErrorInvalidValue;
+}
+
+static inline unsigned grid_for(u64 threads, unsigned block, unsigned cap) {
+  u64 b = (threads + block - 1) / block;
+  if (b < 1) b = 1;
+  if (cap && b > cap) b = cap;
+  return (unsigned)b;
+}
+
+hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, hipStream_t s) {
+  return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
+    typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+    const T *vox = (const T *)w.vox;
+    const u64 nrows = (u64)g.ny * g.nzb;
+    const bool aligned = ((uintptr_t)vox % 16) == 0;
+    if (g.nx % 64 == 0 && aligned) {
+      constexpr int VPL = 16 / sizeof(T);
+      constexpr int U = 4;
+      const u64 nwordsAll = nrows * g.W;
+      const u64 nchunks = nwordsAll / VPL;        // whole 1 KiB chunks; the < VPL words left go below
+      if (nchunks) {
+        // 256 CUs x 8 blocks of 256 threads; grid-stride over the rest
+        const unsigned blocks = grid_for((nchunks + U - 1) / U * 64, 256, 2048);
+        hipLaunchKernelGGL((k_classify_flat<T, U>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nchunks, iso, w.sliceOcc,
+                           (u64)g.ny * g.W);
+      }
+      if (nchunks * VPL < nwordsAll)
+        hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, nchunks * VPL, nrows,
+                           (u64)g.ny, iso, w.sliceOcc);
+    } else {
+      const u64 total = nrows * g.W;
+      const unsigned blocks = grid_for(total * 64, 256, 8192);
+      hipLaunchKernelGGL((k_classify_rows<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, g.nx, g.W, (u64)0, nrows,
+                         (u64)g.ny, iso, w.sliceOcc);
+    }
+    return hipGetLastError();
+  });
+}
+
+hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s) {
+  hipLaunchKernelGGL(k_alias, dim3(1), dim3(64), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
+  return hipGetLastError();
+}
+
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
+  const unsigned blocks = grid_for(nwords, 256, 0);
+  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.alias, g, nwords, w.prefix, w.segV, w.segQ);
+  return hipGetLastError();
+}
+
+size_t scan_temp_bytes(size_t nseg) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const u64 *)nullptr, (u64 *)nullptr, (int)nseg);
+  return bytes;
+}
+
+hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, size_t n, hipStream_t s) {
+  return hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, out, (int)n, s);
+}
+
+hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ, g, nwords,
+                     w.totals);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles, u64 pointOffset, u64 cellOffset,
+                       hipStream_t s) {
+  (void)cellOffset;   // cell ids are positions in this rank's buffer; only point ids are global
+  EmitArgs a;
+  a.bits = w.bits; a.alias = w.alias; a.prefix = w.prefix;
+  a.segBaseV = w.segBaseV; a.segBaseQ = w.segBaseQ; a.tot = w.totals;
+  a.points = w.points;
+  a.cells = triangles ? w.quads : w.cells;
+  a.pointOffset = pointOffset;
+  const size_t nwordsCounted = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const unsigned blocks = grid_for(nwordsCounted, 256, 0);
+  hipLaunchKernelGGL(k_emit_words, dim3(blocks), dim3(256), 0, s, a, g, geo, nwordsCounted);
+  return hipGetLastError();
+}
+
+hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const Params &p, u64 nPoints,
+                          u64 nGhost, hipStream_t s) {
+  if (nPoints == 0) return hipSuccess;
+  return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
+    typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+    const unsigned blocks = grid_for(nPoints, 256, 0);
+    hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, w.points, nPoints,
+                       nGhost, w.totals);
+    return hipGetLastError();
+  });
+}
+
+hipError_t launch_triangulate(const Workspace &w, u64 nQuads, u64 pointOffset, u64 nGhost, hipStream_t s) {
+  if (nQuads == 0) return hipSuccess;
+  const unsigned blocks = grid_for(nQuads, 256, 0);
+  hipLaunchKernelGGL(k_triangulate, dim3(blocks), dim3(256), 0, s, w.quads, w.points, w.cells, nQuads, pointOffset, nGhost);
+  return hipGetLastError();
+}
+
+}  // namespace cuberille

@@ -1,0 +1,72 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    o = graft.load_oracle()
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def ctest_cases():
+    with open(os.path.join(GOLDEN, "ctest_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def volumes(pkg):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pkg.read_mha(os.path.join(GOLDEN, "data", name))
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def extractor(pkg):
+    """One GPU context shared by the -m gpu tests (they run in one process)."""
+    pkg._abi.build()
+    ex = pkg.Extractor(0)
+    yield ex
+    ex.close()
+
+
+def assert_same_mesh(mesh, ref, coords="bits"):
+    """GPU mesh vs oracle mesh: identical ids and cell order; coordinates bit-identical
+    (or within the stated relative tolerance when coords is a float)."""
+    assert mesh.points.shape == ref.points.shape, (mesh.points.shape, ref.points.shape)
+    assert mesh.cells.shape == ref.cells.shape, (mesh.cells.shape, ref.cells.shape)
+    assert np.array_equal(mesh.cells, ref.cells), "cell topology / order differs"
+    if coords == "bits":
+        a = mesh.points.view(np.uint32)
+        b = ref.points.view(np.uint32)
+        nan = np.isnan(mesh.points) & np.isnan(ref.points)
+        bad = (a != b) & ~nan
+        assert not bad.any(), "%d coordinates differ bitwise, first at %s" % (bad.sum(), np.argwhere(bad)[0])
+    else:
+        np.testing.assert_allclose(mesh.points, ref.points, rtol=coords, atol=0)

@@ -1,0 +1,216 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's
+known-answer table.  Bar: identical vertex ids, cell order and counts; coordinates
+bit-identical to the oracle (the north star only asks for 1e-5 relative)."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(pkg, extractor, vol, iso, **kw):
+    prm = pkg.make_params(iso, **kw)
+    extractor.extract_host(vol, prm)
+    return extractor.download()
+
+
+def test_reference_ctest_table(pkg, extractor, volumes, ctest_cases):
+    """The 19 pinned (points, cells) pairs of Testing/CMakeLists.txt:10-331."""
+    for c in ctest_cases:
+        vol = volumes(c["input"])
+        mesh = run_gpu(pkg, extractor, vol, c["iso"], triangles=c["triangles"], project=c["project"],
+                       threshold=c["threshold"], step=c["step"], relax=c["relax"], max_steps=c["max_steps"])
+        assert mesh.GetNumberOfPoints() == c["points"], c["name"]
+        assert mesh.GetNumberOfCells() == c["cells"], c["name"]
+
+
+@pytest.mark.parametrize("name,iso,max_steps", [
+    ("blob0.mha", 200, 100), ("blob1.mha", 200, 100), ("blob2.mha", 200, 100), ("blob3.mha", 200, 100),
+    ("blob4.mha", 200, 100), ("marschnerlobb.mha", 55, 200), ("fuel.mha", 15, 100), ("hydrogenAtom.mha", 15, 100),
+    ("neghip.mha", 55, 100), ("nucleon.mha", 140, 100), ("silicium.mha", 85, 100)])
+def test_data_volumes_match_oracle(pkg, oracle, extractor, volumes, name, iso, max_steps):
+    """Every Data/*.mha at its CTest iso: ids, order and float bits equal the oracle's for
+    quads/triangles x projection off/on."""
+    vol = volumes(name)
+    for tri in (0, 1):
+        for proj in (0, 1):
+            kw = dict(triangles=tri, project=proj, threshold=0.2, step=0.24, relax=0.95, max_steps=max_steps)
+            mesh = run_gpu(pkg, extractor, vol, iso, **kw)
+            ref = oracle.run(vol.voxels, iso, **kw)
+            assert_same_mesh(mesh, ref)
+
+
+@pytest.mark.parametrize("name,points,quads", [("nucleon.mha", 3640, 3636), ("fuel.mha", 1218, 1208),
+                                               ("marschnerlobb.mha", 14726, 15744)])
+def test_baseline_configs_1_and_2(pkg, oracle, extractor, volumes, name, points, quads):
+    """BASELINE.json configs[0..1]: iso 128 ("50 %"), CLI defaults of CuberilleTest01.cxx:98-109."""
+    vol = volumes(name)
+    mesh = run_gpu(pkg, extractor, vol, 128)
+    ref = oracle.run(vol.voxels, 128)
+    assert mesh.GetNumberOfPoints() == points and mesh.GetNumberOfCells() == 2 * quads
+    assert_same_mesh(mesh, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(5, 6, 7), (9, 8, 64), (6, 5, 128), (7, 9, 130), (4, 3, 200), (12, 11, 63)])
+def test_random_noise_volumes(pkg, oracle, extractor, dtype, shape):
+    """White noise: every voxel is surface, the image border is inside (quirk Q2), ragged x
+    sizes take both classify paths (nx % 64 == 0 and not)."""
+    rng = np.random.default_rng(hash((np.dtype(dtype).name, shape)) % (2 ** 32))
+    if np.dtype(dtype).kind == "f":
+        vox = rng.normal(0.0, 1.0, size=shape).astype(dtype)
+        iso = 0.25
+    else:
+        info = np.iinfo(dtype)
+        vox = rng.integers(max(info.min, -100), min(info.max, 100), size=shape, endpoint=True).astype(dtype)
+        iso = 10
+    vol = pkg.Volume(vox)
+    for tri in (0, 1):
+        kw = dict(triangles=tri, project=1, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
+        mesh = run_gpu(pkg, extractor, vol, iso, **kw)
+        ref = oracle.run(vox, iso, **kw)
+        assert_same_mesh(mesh, ref)
+
+
+def test_sparse_volumes_empty_slice_aliasing(pkg, oracle, extractor):
+    """Quirk Q1: an empty slice between occupied slices makes the reference re-use the ids of the
+    slice below (txx:139-141 precede 156-161).  Sparse random volumes hit it constantly."""
+    rng = np.random.default_rng(7)
+    hits = 0
+    for trial in range(40):
+        shape = (int(rng.integers(4, 14)), int(rng.integers(3, 12)), int(rng.choice([5, 64, 70, 130])))
+        vox = (rng.random(shape) < rng.choice([0.002, 0.01, 0.05])).astype(np.uint8) * 255
+        # blank whole slices to force gaps
+        for z in range(shape[0]):
+            if rng.random() < 0.4:
+                vox[z] = 0
+        vol = pkg.Volume(vox)
+        mesh = run_gpu(pkg, extractor, vol, 128, triangles=1, project=0)
+        ref = oracle.run(vox, 128, triangles=True, project=False)
+        assert_same_mesh(mesh, ref)
+        p_closed, _ = oracle.closed_form_counts(vox, 128)
+        hits += int(p_closed != len(ref.points))
+    assert hits > 0, "no trial exercised the aliasing quirk"
+
+
+def test_quirk_micro_volumes(pkg, oracle, extractor):
+    # Q1: two isolated voxels two slices apart -> 12 points instead of 16
+    vox = np.zeros((10, 8, 8), dtype=np.uint8)
+    vox[5, 3, 3] = 255
+    vox[7, 3, 3] = 255
+    mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 128, triangles=0, project=0)
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (12, 12)
+    assert_same_mesh(mesh, oracle.run(vox, 128, triangles=False, project=False))
+    # same volume with the emulation switched off: the geometrically expected 16 points
+    mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 128, triangles=0, project=0, q1=False)
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (16, 12)
+    # Q2: inside voxel in the image corner -> 7 points, 3 quads; all-inside volume -> empty mesh
+    vox = np.zeros((4, 4, 4), dtype=np.uint8)
+    vox[0, 0, 0] = 255
+    mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 128, triangles=0, project=0)
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (7, 3)
+    assert_same_mesh(mesh, oracle.run(vox, 128, triangles=False, project=False))
+    vox[:] = 255
+    mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 128)
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (0, 0)
+    # 1x1x1 and all-outside
+    mesh = run_gpu(pkg, extractor, pkg.Volume(np.zeros((1, 1, 1), dtype=np.uint8)), 128)
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (0, 0)
+
+
+def test_zero_gradient_plateau_goes_nan_like_the_oracle(pkg, oracle, extractor):
+    """Quirk Q4: Normalize() has no zero guard (txx:452).  A flat plateau gives a zero gradient at
+    vertices that are not within the threshold: NaN coordinates on both sides."""
+    vox = np.zeros((9, 9, 9), dtype=np.float32)
+    vox[2:7, 2:7, 2:7] = 10.0
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.25, relax=0.95, max_steps=20)
+    mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 5.0, **kw)
+    ref = oracle.run(vox, 5.0, **kw)
+    assert np.array_equal(np.isnan(mesh.points), np.isnan(ref.points))
+    assert_same_mesh(mesh, ref)
+
+
+def test_anisotropic_geometry(pkg, oracle, extractor, volumes):
+    """Spacing, origin and a rotated direction matrix go through I3/I4/I6 on both sides."""
+    src = volumes("nucleon.mha")
+    th = 0.3
+    direction = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    vol = pkg.Volume(src.voxels, spacing=(0.5, 1.25, 2.0), origin=(-3.0, 10.5, 0.125), direction=direction)
+    kw = dict(triangles=1, project=1, threshold=0.2, step=-1.0, relax=0.95, max_steps=60)
+    mesh = run_gpu(pkg, extractor, vol, 128, **kw)
+    ref = oracle.run(vol.voxels, 128, spacing=vol.spacing, origin=vol.origin, direction=vol.direction, **kw)
+    assert_same_mesh(mesh, ref)
+
+
+def test_packed_bits_match_threshold(pkg, extractor):
+    rng = np.random.default_rng(3)
+    for shape in [(3, 4, 70), (2, 3, 128), (5, 2, 64)]:
+        vox = rng.integers(0, 255, size=shape, dtype=np.uint8)
+        vol = pkg.Volume(vox)
+        extractor.extract_host(vol, pkg.make_params(100, project=False))
+        words = extractor.debug_bits(vol.dims)
+        nx = shape[2]
+        bits = np.unpackbits(words.view(np.uint8), axis=-1, bitorder="little")[..., :nx].astype(bool)
+        assert np.array_equal(bits, vox >= 100)
+        tail = np.unpackbits(words.view(np.uint8), axis=-1, bitorder="little")[..., nx:]
+        assert not tail.any()
+
+
+def test_slabs_concatenate_to_the_whole(pkg, oracle, extractor, volumes):
+    """The multi-GPU decomposition on one device: Z-slabs with halo, per-slab counts, prefix of the
+    counts as id offsets, concatenation == single-shot result == oracle."""
+    import torch
+    for name, iso, cuts in [("nucleon.mha", 128, [0, 13, 14, 30, 41]), ("fuel.mha", 15, [0, 34, 68]),
+                            ("silicium.mha", 85, [0, 7, 19, 20, 40])]:
+        vol = volumes(name)
+        nx, ny, nz = vol.dims
+        for tri in (0, 1):
+            kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+            ref = oracle.run(vol.voxels, iso, **kw)
+            prm = pkg.make_params(iso, **kw)
+            pts, cells, poff = [], [], 0
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                lo, hi = max(a - 8, 0), min(b + 8, nz)
+                slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+                desc = pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo))
+                slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
+                n_p, n_c = extractor.count(slab_vox.data_ptr(), desc, prm, slab)
+                extractor.emit(poff, 0)
+                m = extractor.download()
+                assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
+                pts.append(m.points)
+                cells.append(m.cells)
+                poff += n_p
+            whole = pkg.Mesh(np.concatenate(pts), np.concatenate(cells))
+            assert_same_mesh(whole, ref)
+
+
+def test_512_sphere_properties(pkg, extractor):
+    """BASELINE.json configs[2] at full size, through size-independent properties: counts equal the
+    closed form evaluated with numpy, the mesh is a closed 2-manifold of genus 0 (V - E + F = 2),
+    every projected vertex lies within the threshold of the iso-surface (|f| < thr, f exact SDF)."""
+    import torch
+    n = 512
+    vol = pkg.volumes.sphere_sdf(n, xp=torch, device="cuda")
+    desc = pkg.make_desc(np.float32, (n, n, n))
+    prm = pkg.make_params(0.0, triangles=False, project=True, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
+    extractor.extract_device(vol.data_ptr(), desc, prm)
+    mesh = extractor.download()
+    ins = (vol >= 0).cpu().numpy()
+    quads = 0
+    for ax in range(3):
+        a = np.moveaxis(ins, ax, 0)
+        quads += int(np.count_nonzero(a[1:] != a[:-1]))
+    assert mesh.GetNumberOfCells() == quads
+    V, F = mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()
+    q = mesh.cells.astype(np.int64)
+    e = np.concatenate([np.stack([q[:, i], q[:, (i + 1) % 4]], 1) for i in range(4)])
+    e.sort(axis=1)
+    E = np.unique(e, axis=0).shape[0]
+    assert V - E + F == 2
+    assert E * 2 == F * 4                       # every edge shared by exactly two quads
+    c = (n - 1) / 2.0
+    p = mesh.points.astype(np.float64) - np.array([c + 0.25, c + 0.125, c + 0.0625])
+    dist = np.abs(0.4 * n - np.sqrt((p * p).sum(1)))
+    assert dist.max() < 0.06                    # thr 0.05 on the trilinear field ~ exact SDF to <0.01
