@@ -68,9 +68,9 @@ def gather_counts(n_points, n_cells, device, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     mine = torch.tensor([int(n_points), int(n_cells)], dtype=torch.int64, device=device)
-    out = torch.empty((world, 2), dtype=torch.int64, device=device)
+    out = torch.empty(world * 2, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine, group=group)
-    return out.cpu().numpy()
+    return out.cpu().numpy().reshape(world, 2)
 
 
 def id_offsets(counts, rank):

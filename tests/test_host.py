@@ -1,0 +1,125 @@
+"""CPU tests of the host side: the C-ABI library builds for gfx950 without a GPU, loads, exports
+every symbol include/cuberille_hip.h declares and fails loudly (no fallback) when there is no
+device; the filter mirror keeps the reference's defaults and clamps; MHA io; volume generators."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu(pkg):
+    return pkg._abi.lib().cuberille_device_count() > 0
+
+
+def test_library_builds_and_exports_the_whole_header(pkg):
+    pkg._abi.build()
+    lib = pkg._abi.lib()
+    header = open(os.path.join(ROOT, "include", "cuberille_hip.h")).read()
+    declared = set(re.findall(r"\b(cuberille_[a-z_]+)\s*\(", header))
+    assert declared == set(pkg._abi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.cuberille_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(pkg):
+    assert C.sizeof(pkg._abi.ImageDesc) == 8 + 24 + 24 + 24 + 72
+    assert C.sizeof(pkg._abi.Params) == 8 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(pkg._abi.Slab) == 48
+    assert C.sizeof(pkg._abi.Result) == 8 + 8 + 8 + 7 * 4 + 4 + 8
+
+
+def test_no_device_means_error_not_fallback(pkg):
+    if _has_gpu(pkg):
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        pkg.Extractor(0)
+    assert e.value.code == pkg._abi.ERR_NO_DEVICE
+    f = pkg.CuberilleImageToMeshFilter()
+    f.SetInput(pkg.Volume(np.zeros((4, 4, 4), dtype=np.uint8)))
+    with pytest.raises(pkg._abi.CuberilleError):
+        f.Update()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg_dir = os.path.join(ROOT, "midas-journal-740_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".cxx", ".txx")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle/" not in text and "import oracle" not in text and "cuberille_oracle" not in text, fn
+
+
+def test_filter_defaults_and_clamps(pkg):
+    f = pkg.CuberilleImageToMeshFilter()
+    # txx:33-40
+    assert f.GetIsoSurfaceValue() == 1
+    assert f.GetGenerateTriangleFaces() is True and f.GetProjectVerticesToIsoSurface() is True
+    assert f.GetProjectVertexSurfaceDistanceThreshold() == 0.5
+    assert f.GetProjectVertexStepLength() == -1.0
+    assert f.GetProjectVertexStepLengthRelaxationFactor() == 0.95
+    assert f.GetProjectVertexMaximumNumberOfSteps() == 50
+    # h:210,216,223
+    f.SetInput(pkg.Volume(np.zeros((2, 2, 2), dtype=np.uint8)))
+    f.SetProjectVertexSurfaceDistanceThreshold(1e9)
+    assert f.GetProjectVertexSurfaceDistanceThreshold() == 255.0
+    f.SetProjectVertexSurfaceDistanceThreshold(-1)
+    assert f.GetProjectVertexSurfaceDistanceThreshold() == 0.0
+    f.SetProjectVertexStepLength(1e9)
+    assert f.GetProjectVertexStepLength() == 100000.0
+    f.SetProjectVertexStepLengthRelaxationFactor(3)
+    assert f.GetProjectVertexStepLengthRelaxationFactor() == 1.0
+    f.GenerateTriangleFacesOff()
+    assert f.GetGenerateTriangleFaces() is False
+    f.ProjectVerticesToIsoSurfaceOff()
+    assert f.GetProjectVerticesToIsoSurface() is False
+    g = pkg.CuberilleImageToMeshFilter()
+    with pytest.raises(RuntimeError):
+        g.Update()                      # missing required input
+
+
+def test_mha_reader_on_reference_data(pkg, volumes):
+    v = volumes("nucleon.mha")
+    assert v.dims == (41, 41, 41) and v.voxels.dtype == np.uint8
+    assert v.spacing == (1.0, 1.0, 1.0) and v.origin == (0.0, 0.0, 0.0)
+    assert np.array_equal(v.direction, np.eye(3))
+    assert volumes("silicium.mha").dims == (104, 40, 40)
+    assert int((v.voxels >= 140).sum()) == 6996          # SURVEY.md section 4 [PROBE]
+
+
+def test_mha_roundtrip(pkg, tmp_path):
+    rng = np.random.default_rng(5)
+    for dt in (np.uint8, np.int16, np.float32):
+        vox = (rng.random((3, 4, 5)) * 100).astype(dt)
+        vol = pkg.Volume(vox, spacing=(0.5, 1.5, 2.0), origin=(1.0, 2.0, 3.0))
+        for compress in (True, False):
+            p = str(tmp_path / ("v_%s_%d.mha" % (np.dtype(dt).name, compress)))
+            pkg.write_mha(p, vol, compress)
+            back = pkg.read_mha(p)
+            assert np.array_equal(back.voxels, vox) and back.spacing == vol.spacing and back.origin == vol.origin
+
+
+def test_volume_generators_numpy_vs_torch(pkg):
+    import torch
+    vol = pkg.volumes
+    a = vol.sphere_sdf(24, 3, 17)
+    b = vol.sphere_sdf(24, 3, 17, xp=torch).numpy()
+    assert a.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    a = vol.gradient_noise(70, 33, 40, 5, 29)
+    b = vol.gradient_noise(70, 33, 40, 5, 29, xp=torch).numpy()
+    assert a.dtype == np.uint8 and np.array_equal(a, b)
+    assert a.std() > 5 and 20 < a.mean() < 235
+    m = vol.marschner_lobb(32)
+    assert m.dtype == np.float32 and m[0].max() == 0 and m[:, 0].max() == 0 and m[:, :, -1].max() == 0
+    assert 0.0 <= m.min() and m.max() <= 1.0 and (m[1:-1, 1:-1, 1:-1] > 0.5).any()
+    # slabs of the generators tile the whole volume
+    whole = vol.marschner_lobb(32)
+    parts = np.concatenate([vol.marschner_lobb(32, 0, 10), vol.marschner_lobb(32, 10, 32)])
+    assert np.array_equal(whole, parts)
+    stacked = vol.marschner_lobb(16, 0, 32, period=16)
+    assert np.allclose(stacked[:16], stacked[16:]) and np.allclose(stacked[:16], vol.marschner_lobb(16))

@@ -1,0 +1,141 @@
+"""CPU tests of the oracle (the checker): pinned against every known-answer vector the reference
+holds for the hot path, cross-checked against an independent numpy closed form, plus the [ITK]
+contract pieces one by one (H7)."""
+import numpy as np
+import pytest
+
+
+def test_reference_ctest_table(oracle, volumes, ctest_cases):
+    """All 19 (points, cells) pairs of /root/reference/Testing/CMakeLists.txt:10-331."""
+    assert len(ctest_cases) == 19
+    for c in ctest_cases:
+        vol = volumes(c["input"])
+        m = oracle.run(vol.voxels, c["iso"], c["triangles"], c["project"], c["threshold"], c["step"], c["relax"],
+                       c["max_steps"])
+        assert len(m.points) == c["points"], c["name"]
+        assert len(m.cells) == c["cells"], c["name"]
+
+
+def test_closed_form_counts_agree_on_data(oracle, volumes, ctest_cases):
+    for name, iso in sorted({(c["input"], c["iso"]) for c in ctest_cases}):
+        vol = volumes(name)
+        m = oracle.run(vol.voxels, iso, triangles=False, project=False)
+        assert (len(m.points), len(m.cells)) == oracle.closed_form_counts(vol.voxels, iso)
+
+
+def test_baseline_iso_values(oracle, volumes):
+    """Counts at BASELINE.json's iso 128 (derived)."""
+    for name, pts, quads in [("nucleon.mha", 3640, 3636), ("fuel.mha", 1218, 1208), ("marschnerlobb.mha", 14726, 15744)]:
+        m = oracle.run(volumes(name).voxels, 128)
+        assert (len(m.points), len(m.cells)) == (pts, 2 * quads)
+
+
+def test_closed_form_on_dense_random_volumes(oracle):
+    """Dense noise never leaves a slice empty, so the closed form must hold (also on the border: Q2)."""
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        shape = tuple(int(v) for v in rng.integers(2, 12, size=3))
+        vox = rng.integers(0, 255, size=shape, dtype=np.uint8)
+        m = oracle.run(vox, 128, triangles=False, project=False)
+        if (vox >= 128).any(axis=(1, 2)).all():
+            assert (len(m.points), len(m.cells)) == oracle.closed_form_counts(vox, 128)
+
+
+def test_quirks(oracle):
+    vox = np.zeros((10, 8, 8), dtype=np.uint8)
+    vox[5, 3, 3] = vox[7, 3, 3] = 255                       # Q1: 12 points instead of 16
+    m = oracle.run(vox, 128, triangles=False, project=False)
+    assert (len(m.points), len(m.cells)) == (12, 12)
+    vox = np.zeros((4, 4, 4), dtype=np.uint8)
+    vox[0, 0, 0] = 255                                       # Q2: open border
+    m = oracle.run(vox, 128, triangles=False, project=False)
+    assert (len(m.points), len(m.cells)) == (7, 3)
+    vox[:] = 255
+    m = oracle.run(vox, 128)
+    assert (len(m.points), len(m.cells)) == (0, 0)
+
+
+def test_topology_blob_cases(oracle, volumes):
+    """blob0 is one voxel: its 8 corners in corner order, 6 quads in face order (txx:197-202)."""
+    vol = volumes("blob0.mha")
+    m = oracle.run(vol.voxels, 200, triangles=False, project=False)
+    z, y, x = (int(v[0]) for v in np.nonzero(vol.voxels >= 200))
+    VO = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    want = np.array([(x + a - 0.5, y + b - 0.5, z + c - 0.5) for a, b, c in VO], dtype=np.float32)
+    assert np.array_equal(m.points, want)
+    assert m.cells.tolist() == [[0, 4, 7, 3], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [0, 3, 2, 1], [4, 5, 6, 7]]
+    # unprojected unit quads always tie on the diagonal test -> first split form (txx:298-302)
+    t = oracle.run(vol.voxels, 200, triangles=True, project=False)
+    assert t.cells[:2].tolist() == [[0, 4, 3], [4, 7, 3]]
+
+
+def test_interpolation_contract(oracle):
+    rng = np.random.default_rng(0)
+    vox = rng.random((5, 6, 7)).astype(np.float32)
+    # at pixel centres: the pixel itself
+    assert oracle.interpolate(vox, (3.0, 2.0, 1.0)) == float(vox[1, 2, 3])
+    # trilinear weights
+    p = (2.25, 3.5, 1.75)
+    x0, y0, z0 = 2, 3, 1
+    dx, dy, dz = 0.25, 0.5, 0.75
+    want = 0.0
+    for k in range(8):
+        ux, uy, uz = k & 1, (k >> 1) & 1, k >> 2
+        w = (dx if ux else 1 - dx) * (dy if uy else 1 - dy) * (dz if uz else 1 - dz)
+        want += w * float(vox[z0 + uz, y0 + uy, x0 + ux])
+    assert oracle.interpolate(vox, p) == pytest.approx(want, rel=1e-15)
+    # outside the image: clamped neighbours, no exception
+    assert np.isfinite(oracle.interpolate(vox, (-3.0, 100.0, 2.0)))
+    # geometry: spacing and origin
+    assert oracle.interpolate(vox, (10.0 + 3 * 0.5, -1.0 + 2 * 2.0, 1 * 1.5), spacing=(0.5, 2.0, 1.5),
+                              origin=(10.0, -1.0, 0.0)) == float(vox[1, 2, 3])
+
+
+def test_gradient_contract(oracle):
+    vox = np.arange(4 * 5 * 6, dtype=np.float32).reshape(4, 5, 6) ** 1.5
+    g = oracle.gradient_at_index(vox, (2, 2, 1))
+    want = [(vox[1, 2, 3] - vox[1, 2, 1]) / 2, (vox[1, 3, 2] - vox[1, 1, 2]) / 2, (vox[2, 2, 2] - vox[0, 2, 2]) / 2]
+    assert np.allclose(g, want, rtol=1e-6)
+    # ZeroFluxNeumann border: one-sided difference halved
+    g = oracle.gradient_at_index(vox, (0, 0, 0))
+    assert np.allclose(g, [(vox[0, 0, 1] - vox[0, 0, 0]) / 2, (vox[0, 1, 0] - vox[0, 0, 0]) / 2,
+                           (vox[1, 0, 0] - vox[0, 0, 0]) / 2], rtol=1e-6)
+    # spacing scales the derivative
+    g2 = oracle.gradient_at_index(vox, (2, 2, 1), spacing=(2.0, 1.0, 0.5))
+    assert np.allclose(g2, [want[0] / 2, want[1], want[2] * 2], rtol=1e-6)
+
+
+def test_index_to_point(oracle):
+    vox = np.zeros((2, 2, 2), dtype=np.uint8)
+    p = oracle.index_to_point(vox, (3, 4, 5), spacing=(0.5, 2.0, 1.0), origin=(1.0, -2.0, 0.25))
+    assert np.array_equal(p, np.array([2.5, 6.0, 5.25], dtype=np.float32))
+
+
+def test_projection_moves_vertices_onto_the_surface(oracle):
+    n = 24
+    z, y, x = np.meshgrid(*(np.arange(n, dtype=np.float64),) * 3, indexing="ij")
+    c = (n - 1) / 2
+    sdf = (8.0 - np.sqrt((x - c - 0.25) ** 2 + (y - c - 0.125) ** 2 + (z - c) ** 2)).astype(np.float32)
+    m = oracle.run(sdf, 0.0, triangles=True, project=True, threshold=0.02, step=0.25, relax=0.95, max_steps=50)
+    r = np.sqrt(((m.points - np.array([c + 0.25, c + 0.125, c], dtype=np.float32)) ** 2).sum(1))
+    assert np.abs(r - 8.0).max() < 0.05
+    assert m.info["proj_stop_threshold"] == len(m.points)
+    # triangles: two per quad, every triangle uses three distinct vertices
+    assert (m.cells[:, 0] != m.cells[:, 1]).all() and (m.cells[:, 1] != m.cells[:, 2]).all()
+
+
+def test_pixel_types_agree(oracle, volumes):
+    """The template is instantiated per pixel type; integer types must give identical meshes."""
+    vox = volumes("nucleon.mha").voxels
+    ref = oracle.run(vox, 128)
+    for dt in (np.int16, np.uint16, np.int32, np.uint32, np.float32, np.float64):
+        m = oracle.run(vox.astype(dt), 128)
+        assert np.array_equal(m.cells, ref.cells)
+        assert np.array_equal(m.points.view(np.uint32), ref.points.view(np.uint32))
+
+
+def test_faithful_cells_mode_is_identical(oracle, volumes):
+    vox = volumes("fuel.mha").voxels
+    a = oracle.run(vox, 15, faithful_cells=False, gradient_threads=1)
+    b = oracle.run(vox, 15, faithful_cells=True, gradient_threads=4)
+    assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))
