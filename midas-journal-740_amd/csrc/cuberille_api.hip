@@ -295,6 +295,7 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
 int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit called before a successful cuberille_count");
+  (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 nV = c->tot.totV;                 // ghost + owned
   const u64 nGhost = c->tot.V0;
@@ -308,7 +309,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   w.quads = (u64 *)c->quads.p;
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  HIP_TRY(c, launch_emit(w, c->g, c->geo, c->prm.triangles, point_id_offset, cell_id_offset, s));
+  HIP_TRY(c, launch_emit(w, c->g, c->geo, c->prm.triangles, point_id_offset, nV, nQ, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));
   HIP_TRY(c, hipEventRecord(c->ev[6], s));

@@ -74,7 +74,7 @@ hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles,
-                       u64 pointOffset, u64 cellOffset, hipStream_t s);
+                       u64 pointOffset, u64 nV, u64 nQ, hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, hipStream_t s);
 hipError_t launch_triangulate(const Workspace &w, u64 nQuads, u64 pointOffset, u64 nGhost, hipStream_t s);

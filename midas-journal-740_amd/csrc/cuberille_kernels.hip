@@ -379,85 +379,137 @@ __device__ u64 corner_id_generic(const EmitArgs &a, const Grid &g, int cx, int c
   return id;
 }
 
-// v0 emit: one lane per word, serial over the word's surface voxels.  Correct for every case
-// (including the empty-slice aliasing); the LDS-tiled kernel replaces it on the fast path.
-// Words of the counted slice below the owned range (a slab's ghost slice) only write their points:
-// the rank above needs those coordinates for the triangle split of its first slice.
-__global__ __launch_bounds__(256) void k_emit_words(EmitArgs a, Grid g, Geo geo, size_t nwordsCounted) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nwordsCounted) return;
-  const size_t row = t / g.W;
-  const int k = (int)(t % g.W);
+// Inverse mapping: output index -> source.  Every output (vertex v, quad q) has exactly one
+// producing voxel; ids are positions in the raster-ordered enumeration, so the producer is found
+// by searching the prefix arrays: segment (binary search over the scanned segment bases), word
+// (binary search over the in-segment exclusive prefixes), voxel and corner/face inside the word
+// (popcount prefix over the word's masks).  One lane per OUTPUT keeps every lane busy; the
+// surface is ~1 % of the voxels, so a lane per voxel (or per word) would idle almost all lanes.
+template <int SHIFT>
+__device__ __forceinline__ size_t locate_word(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
+                                              size_t nseg, size_t nwords, u64 idx, u32 &within) {
+  size_t lo = 0, hi = nseg;                      // largest seg with segBase[seg] <= idx
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) >> 1;
+    if (segBase[mid] <= idx) lo = mid; else hi = mid;
+  }
+  const u32 r = (u32)(idx - segBase[lo]);
+  size_t wlo = lo << 6, whi = wlo + 64;
+  if (whi > nwords) whi = nwords;
+  while (whi - wlo > 1) {                        // largest word with prefix <= r (skips empty words)
+    const size_t mid = (wlo + whi) >> 1;
+    if (((prefix[mid] >> SHIFT) & 0xffffu) <= r) wlo = mid; else whi = mid;
+  }
+  within = r - ((prefix[wlo] >> SHIFT) & 0xffffu);
+  return wlo;
+}
+
+// position of the set bit of rank r (0-based) in an 8-bit mask
+__device__ __forceinline__ int select_bit8(unsigned m, int r) {
+  for (int i = 0; i < r; i++) m &= m - 1;
+  return __ffs((int)m) - 1;
+}
+
+// K3a: one lane per vertex of the counted range (a slab's ghost slice included: the rank above
+// needs those coordinates for the triangle split of its first slice).
+__global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo, size_t nseg, size_t nwords, u64 nV) {
+  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nV) return;
+  u32 r;
+  const size_t gi = locate_word<0>(a.segBaseV, a.prefix, nseg, nwords, v, r);
+  const size_t row = gi / g.W;
+  const int k = (int)(gi % g.W);
   const int y = (int)(row % g.ny);
   const int z = g.cz0 + (int)(row / g.ny);
-  const bool owned = z >= g.oz0;
   WordInfo w;
   classify_word(a.bits, a.alias, g, y, z, k, w);
-  u64 active = w.F[0] | w.F[1] | w.F[2] | w.F[3] | w.F[4] | w.F[5];
-  if (!active) return;
-  const size_t gi = t;
-  // ids are global: subtract what was counted below the owned range, add this rank's offset
-  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
-  const u64 baseV = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);
-  const u64 baseQ = a.segBaseQ[gi >> 6] + (a.prefix[gi] >> 16);
-  const int zp = a.alias[z];
-  while (active) {
-    const int bx = __ffsll((long long)active) - 1;
-    active &= active - 1;
-    const int x = k * 64 + bx;
-    unsigned cm = 0, fm = 0;
-    u64 first = baseV;
+  int lo = 0, hi = 64;                           // largest bit position with (#created before it) <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    int c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      first += popc64(w.C[i] & lowmask(bx));
-      cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
-    }
-    u64 q = baseQ;
-#pragma unroll
-    for (int f = 0; f < 6; f++) {
-      q += popc64(w.F[f] & lowmask(bx));
-      fm |= (unsigned)((w.F[f] >> bx) & 1ull) << f;
-    }
-    unsigned need = 0;
-#pragma unroll
-    for (int f = 0; f < 6; f++) if (fm & (1u << f)) need |= kFaceCornerMask[f];
-    if (!owned) { need &= cm; fm = 0; }
-    u64 vid[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      vid[i] = 0;
-      if (!(need & (1u << i))) continue;
-      const int cx = x + (kCornerEnc[i] & 1), cy = y + ((kCornerEnc[i] >> 1) & 1), cz = z + (kCornerEnc[i] >> 2);
-      if (cm & (1u << i)) {
-        const u64 lid = first + __popc(cm & ((1u << i) - 1u));    // index in the counted range
-        vid[i] = lid - V0 + a.pointOffset;
-        float p[3];
-        corner_point(geo, cx, cy, g.zglob0 + cz, p);
-        float *dst = a.points + 3 * lid;     // ghost points first, owned points from 3*V0 on
-        dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-      } else {
-        int lz = cz;
-        if (i < 4 && zp >= 0) {
-          // bottom corner on an aliased slice: does the (x,y) key exist among zp's top corners?
-          bool hit = false;
-          for (int e = 0; e < 4; e++) {
-            const int vx = cx - (e & 1), vy = cy - (e >> 1);
-            if (vx >= 0 && vx < g.nx && vy >= 0 && vy < g.ny && getbit(a.bits, g, vx, vy, zp)) hit = true;
-          }
-          if (hit) lz = zp + 1;
-        }
-        vid[i] = corner_id_generic(a, g, cx, cy, lz) - V0 + a.pointOffset;
-      }
-    }
-#pragma unroll
-    for (int f = 0; f < 6; f++) {
-      if (!(fm & (1u << f))) continue;
-      u64 *dst = a.cells + 4 * (q - Q0);
-      dst[0] = vid[kFaceCorner[f][0]]; dst[1] = vid[kFaceCorner[f][1]];
-      dst[2] = vid[kFaceCorner[f][2]]; dst[3] = vid[kFaceCorner[f][3]];
-      q++;
-    }
+    for (int i = 0; i < 8; i++) c += popc64(w.C[i] & lowmask(mid));
+    if ((u32)c <= r) lo = mid; else hi = mid;
   }
+  int before = 0;
+  unsigned cm = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    before += popc64(w.C[i] & lowmask(lo));
+    cm |= (unsigned)((w.C[i] >> lo) & 1ull) << i;
+  }
+  const int i = select_bit8(cm, (int)r - before);
+  const int e = kCornerEnc[i];
+  float p[3];
+  corner_point(geo, (long long)k * 64 + lo + (e & 1), y + ((e >> 1) & 1), g.zglob0 + z + (e >> 2), p);
+  float *dst = a.points + 3 * v;                 // ghost points first, owned points from 3*V0 on
+  dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+}
+
+// the six face masks of a word only (7 bit-rows instead of 27)
+__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
+  const Rows3 c = load_row(bits, g, y, z, k);
+  const u64 *base = bits + k;
+  const size_t rs = (size_t)g.W;
+  const u64 ym = base[((size_t)z * g.ny + clampi(y - 1, 0, g.ny - 1)) * rs];
+  const u64 yp = base[((size_t)z * g.ny + clampi(y + 1, 0, g.ny - 1)) * rs];
+  const u64 zm = base[((size_t)clampi(z - 1, 0, g.nzb - 1) * g.ny + y) * rs];
+  const u64 zp = base[((size_t)clampi(z + 1, 0, g.nzb - 1) * g.ny + y) * rs];
+  F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
+}
+
+// K3b: one lane per quad of the owned range.
+__global__ __launch_bounds__(256) void k_emit_quads(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nQ) return;
+  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
+  u32 r;
+  const size_t gi = locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r);
+  const size_t row = gi / g.W;
+  const int k = (int)(gi % g.W);
+  const int y = (int)(row % g.ny);
+  const int z = g.cz0 + (int)(row / g.ny);
+  u64 F[6];
+  faces_word(a.bits, g, y, z, k, F);
+  int lo = 0, hi = 64;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    int c = 0;
+#pragma unroll
+    for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
+    if ((u32)c <= r) lo = mid; else hi = mid;
+  }
+  int before = 0;
+  unsigned fm = 0;
+#pragma unroll
+  for (int f = 0; f < 6; f++) {
+    before += popc64(F[f] & lowmask(lo));
+    fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
+  }
+  const int f = select_bit8(fm, (int)r - before);
+  const int x = k * 64 + lo;
+  const int zp = a.alias[z];
+  u64 ids[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int i = kFaceCorner[f][c];
+    const int e = kCornerEnc[i];
+    const int cx = x + (e & 1), cy = y + ((e >> 1) & 1);
+    int cz = z + (e >> 2);
+    if (i < 4 && zp >= 0) {
+      // bottom corner on an aliased slice (quirk Q1): the reference finds the (x,y) key among the
+      // top corners of slice zp if any voxel of zp touching that corner is inside
+      bool hit = false;
+      for (int ee = 0; ee < 4; ee++) {
+        const int vx = cx - (ee & 1), vy = cy - (ee >> 1);
+        if (vx >= 0 && vx < g.nx && vy >= 0 && vy < g.ny && getbit(a.bits, g, vx, vy, zp)) hit = true;
+      }
+      if (hit) cz = zp + 1;
+    }
+    ids[c] = corner_id_generic(a, g, cx, cy, cz) - V0 + a.pointOffset;
+  }
+  u64 *dst = a.cells + 4 * q;
+  dst[0] = ids[0]; dst[1] = ids[1]; dst[2] = ids[2]; dst[3] = ids[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,12 +566,13 @@ __device__ __forceinline__ void make_cell(const Geo &geo, const long long n[3], 
   }
 }
 
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+
 // I6: GradientImageFilter at one pixel
 template <class T>
-__device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo, long long x, long long y, long long z,
-                                            float out[3]) {
+__device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo, bool dirIdentity, long long x, long long y,
+                                            long long z, float f0, float out[3]) {
   float local[3];
-  const float f0 = (float)s.at(x, y, z);
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const float c = geo.gcoef[a];
@@ -532,6 +585,13 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
     sum += c * fp;
     local[a] = sum;
   }
+  if (dirIdentity && finite_f(local[0]) && finite_f(local[1]) && finite_f(local[2])) {
+    // TransformLocalVectorToPhysicalVector with the identity matrix: 0 + 1*v + 0*w + 0*u, which is
+    // v + 0 for finite inputs (turns -0 into +0 exactly like the general form below)
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[r] = local[r] + 0.0f;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     float sum = 0.0f;
@@ -541,8 +601,12 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
   }
 }
 
+// One lane per vertex.  The eight lattice-site gradients and pixel values of the cell the vertex
+// sits in are kept in registers and only re-gathered when the walk enters another cell (steps are
+// <= a quarter voxel and shrink, so most iterations re-use them): the per-iteration work is then
+// the trilinear weights, 32 multiply-adds, one sqrt and three divides, all in f64.
 template <class T>
-__global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm,
+__global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost,
                                                  Totals *__restrict__ tot) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,28 +619,39 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
     bool done = false;
     double step = prm.step;
     unsigned numberOfSteps = 0;
+    long long kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};     // cell held in registers
+    float G[8][3];
+    double Vd[8];
     while (!done) {
       myIters++;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
       make_cell(geo, n, p, c);
+      if (c.lo[0] != kl[0] || c.lo[1] != kl[1] || c.lo[2] != kl[2] || c.hi[0] != kh[0] || c.hi[1] != kh[1] ||
+          c.hi[2] != kh[2]) {
+#pragma unroll
+        for (unsigned counter = 0; counter < 8; counter++) {
+          const long long nx_ = (counter & 1u) ? c.hi[0] : c.lo[0];
+          const long long ny_ = (counter & 2u) ? c.hi[1] : c.lo[1];
+          const long long nz_ = (counter & 4u) ? c.hi[2] : c.lo[2];
+          const T pix = s.at(nx_, ny_, nz_);
+          Vd[counter] = (double)pix;
+          gradient_at(s, geo, dirIdentity != 0, nx_, ny_, nz_, (float)pix, G[counter]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
+      }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights
       double acc[3] = {0.0, 0.0, 0.0}, value = 0.0, total = 0.0;
 #pragma unroll
       for (unsigned counter = 0; counter < 8; counter++) {
         double overlap = 1.0;
-        long long ni[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          if (counter & (1u << k)) { ni[k] = c.hi[k]; overlap *= c.d[k]; }
-          else                     { ni[k] = c.lo[k]; overlap *= 1.0 - c.d[k]; }
-        }
+        for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
         if (overlap != 0.0 && total != 1.0) {     // "if (overlap)" + "break once total == 1"
-          float gp[3];
-          gradient_at(s, geo, ni[0], ni[1], ni[2], gp);
 #pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += overlap * (double)gp[k];
-          value += overlap * (double)s.at(ni[0], ni[1], ni[2]);
+          for (int k = 0; k < 3; k++) acc[k] += overlap * (double)G[counter][k];
+          value += overlap * Vd[counter];
           total += overlap;
         }
       }
@@ -719,29 +794,31 @@ hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hip
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles, u64 pointOffset, u64 cellOffset,
+hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles, u64 pointOffset, u64 nV, u64 nQ,
                        hipStream_t s) {
-  (void)cellOffset;   // cell ids are positions in this rank's buffer; only point ids are global
   EmitArgs a;
   a.bits = w.bits; a.alias = w.alias; a.prefix = w.prefix;
   a.segBaseV = w.segBaseV; a.segBaseQ = w.segBaseQ; a.tot = w.totals;
   a.points = w.points;
   a.cells = triangles ? w.quads : w.cells;
   a.pointOffset = pointOffset;
-  const size_t nwordsCounted = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const unsigned blocks = grid_for(nwordsCounted, 256, 0);
-  hipLaunchKernelGGL(k_emit_words, dim3(blocks), dim3(256), 0, s, a, g, geo, nwordsCounted);
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const size_t nseg = (nwords + 63) >> 6;
+  if (nV) hipLaunchKernelGGL(k_emit_points, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, a, g, geo, nseg, nwords, nV);
+  if (nQ) hipLaunchKernelGGL(k_emit_quads, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
   return hipGetLastError();
 }
 
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const Params &p, u64 nPoints,
                           u64 nGhost, hipStream_t s) {
   if (nPoints == 0) return hipSuccess;
+  int dirIdentity = 1;
+  for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nPoints, 256, 0);
-    hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, w.points, nPoints,
-                       nGhost, w.totals);
+    hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
+                       nPoints, nGhost, w.totals);
     return hipGetLastError();
   });
 }
