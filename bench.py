@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--workload", default="marschner_lobb", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the cube the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-project", action="store_true")
+    ap.add_argument("--thr", type=float, default=None, help="override the projection threshold (experiments)")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +111,8 @@ def main():
 
     n = args.size
     dtype, iso, thr = WORKLOADS[args.workload]
+    if args.thr is not None:
+        thr = args.thr
     gnz = n * world
     ex = pkg.Extractor(local_rank)
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world)
@@ -132,7 +135,7 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = sh.extract(buf, prm)
-    stage_keys = ["ms_classify", "ms_count", "ms_scan", "ms_emit", "ms_project", "ms_triangulate", "ms_total"]
+    stage_keys = ["ms_classify", "ms_count", "ms_scan", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
     acc = {k: 0.0 for k in stage_keys}
     barrier()
     t0 = time.perf_counter()
@@ -173,7 +176,8 @@ def main():
                                    % (args.workload, n, n, gnz, np.dtype(dtype).name, iso, thr),
                        "per_gpu": "%dx%dx%d slab + %d-slice halo" % (n, n, sh.z1 - sh.z0, 8 if world > 1 else 0),
                        "parallelism": "zslab%d" % world,
-                       "points": n_points, "cells": n_cells},
+                       "points": n_points, "cells": n_cells,
+                       "projection_iterations_rank0": int(res.proj_iterations)},
             "roofline": {"bound": "hbm", "kernel": "k_classify_flat (threshold + bit-pack sweep)",
                          "achieved": round(classify_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(classify_gbs / HBM_PEAK_GBS, 4), "traffic": None,

@@ -93,9 +93,9 @@ typedef struct {
   float ms_classify;        /* threshold + bit-pack sweep over the volume */
   float ms_count;           /* per-word face / created-corner counts */
   float ms_scan;            /* prefix sums */
-  float ms_emit;            /* points + quads scatter */
+  float ms_emit_points;     /* vertex scatter: AddVertex without the projection (txx:256-276) */
   float ms_project;         /* vertex projection (txx:439-474) */
-  float ms_triangulate;     /* quad split (txx:286-321) */
+  float ms_emit_cells;      /* quad / triangle scatter incl. the diagonal split (txx:278-332) */
   float ms_total;           /* first classify launch .. last kernel done */
   uint64_t proj_iterations; /* total iterations of the projection loop */
 } cuberille_result;

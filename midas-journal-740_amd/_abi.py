@@ -42,8 +42,8 @@ class Slab(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("verts_per_cell", C.c_int32),
                 ("reserved", C.c_int32), ("ms_classify", C.c_float), ("ms_count", C.c_float),
-                ("ms_scan", C.c_float), ("ms_emit", C.c_float), ("ms_project", C.c_float),
-                ("ms_triangulate", C.c_float), ("ms_total", C.c_float), ("proj_iterations", C.c_uint64)]
+                ("ms_scan", C.c_float), ("ms_emit_points", C.c_float), ("ms_project", C.c_float),
+                ("ms_emit_cells", C.c_float), ("ms_total", C.c_float), ("proj_iterations", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}

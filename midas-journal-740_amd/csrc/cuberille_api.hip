@@ -42,7 +42,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, quads;
+  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   // state of the last count
@@ -167,7 +167,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->occ, &c->alias, &c->prefix, &c->segV, &c->segQ, &c->segBaseV,
-                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->quads};
+                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -302,18 +302,24 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   const u64 nQ = c->tot.totQ - c->tot.Q0;
   HIP_TRY(c, c->points.reserve((size_t)(nV ? nV : 1) * 3 * sizeof(float)));
   HIP_TRY(c, c->cells.reserve((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
-  if (c->prm.triangles) HIP_TRY(c, c->quads.reserve((size_t)(nQ ? nQ : 1) * 4 * sizeof(u64)));
   Workspace &w = c->w;
   w.points = (float *)c->points.p;
   w.cells = (u64 *)c->cells.p;
-  w.quads = (u64 *)c->quads.p;
+  // dense corner -> vertex map (4 B per lattice corner of the buffer); when it cannot be had
+  // (more than 2^32 vertices, or no memory) the cell kernel recomputes ids instead
+  w.cmap = nullptr;
+  if (nV < 0xffffffffULL) {
+    const size_t mapBytes = (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 1) * sizeof(u32);
+    if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
+    else (void)hipGetLastError();
+  }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  HIP_TRY(c, launch_emit(w, c->g, c->geo, c->prm.triangles, point_id_offset, nV, nQ, s));
+  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));
   HIP_TRY(c, hipEventRecord(c->ev[6], s));
-  if (c->prm.triangles) HIP_TRY(c, launch_triangulate(w, nQ, point_id_offset, nGhost, s));
+  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, point_id_offset, nQ, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -322,9 +328,9 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_scan, c->ev[2], c->ev[3]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit, c->ev[4], c->ev[5]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_triangulate, c->ev[6], c->ev[7]));
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->ev[6], c->ev[7]));
   float a = 0.f, b = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[3]));
   HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));

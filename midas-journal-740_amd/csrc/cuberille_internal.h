@@ -58,7 +58,7 @@ struct Workspace {     // device pointers valid for one count/emit pair
   Totals *totals;
   float *points;
   u64 *cells;
-  u64 *quads;
+  u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
 };
 
 struct Params {
@@ -73,11 +73,10 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s);
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
-hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles,
-                       u64 pointOffset, u64 nV, u64 nQ, hipStream_t s);
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s);
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, hipStream_t s);
-hipError_t launch_triangulate(const Workspace &w, u64 nQuads, u64 pointOffset, u64 nGhost, hipStream_t s);
 size_t scan_temp_bytes(size_t nseg);
 hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, size_t n, hipStream_t s);
 

@@ -25,6 +25,7 @@
 #include "../../include/cuberille_hip.h"
 
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -125,20 +126,19 @@ __global__ __launch_bounds__(256) void k_classify_rows(const T *__restrict__ vox
 // bottom-plane corners of slice z are then looked up among the top-plane corners of zp.
 __global__ void k_alias(const u32 *__restrict__ sliceOcc, int *__restrict__ alias, Grid g, int q1,
                         Totals *__restrict__ tot) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int prev = -1;
-  for (int z = 0; z < g.nzb; z++) {
-    int a = -1;
-    if (sliceOcc[z]) {
-      // (a slab cannot see occupied slices below its buffer: the multi-GPU driver checks the
-      //  gathered per-slice occupancy for that case)
-      if (q1 && z > 0 && !sliceOcc[z - 1] && prev >= 0) a = prev;
-      prev = z;
-    }
-    // the aliased source rows must lie inside the counted range to have ids
-    if (a >= 0 && a < g.cz0 && z >= g.cz0) { atomicOr(&tot->err, (u32)ERRF_ALIAS_UNKNOWN); a = -1; }
-    alias[z] = a;
+  const int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= g.nzb) return;
+  int a = -1;
+  // (a slab cannot see occupied slices below its buffer: the multi-GPU driver checks the gathered
+  //  per-slice occupancy for that case)
+  if (q1 && z > 0 && sliceOcc[z] && !sliceOcc[z - 1]) {
+    int p = z - 2;
+    while (p >= 0 && !sliceOcc[p]) p--;
+    a = p;
   }
+  // the aliased source rows must lie inside the counted range to have ids
+  if (a >= 0 && a < g.cz0 && z >= g.cz0) { atomicOr(&tot->err, (u32)ERRF_ALIAS_UNKNOWN); a = -1; }
+  alias[z] = a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,9 +319,18 @@ struct EmitArgs {
   const u64 *segBaseV, *segBaseQ;
   const Totals *tot;
   float *points;
-  u64 *cells;          // quads (4 ids) -- final cells, or the quad staging buffer when triangulating
+  u64 *cells;          // 4 ids per quad, or 2 x 3 ids per quad when triangulating
   u64 pointOffset;     // global id of this rank's first point
+  u32 *cmap;           // dense lattice-corner -> vertex index map, or null (see corner_map_index)
 };
+
+// The reference finds a corner's id in a std::map keyed by (x,y) per z-plane (h:272-313).  With
+// 288 GB of HBM the MI355X equivalent is a dense array over all (nx+1)(ny+1)(nz+1) lattice corners,
+// never initialised: the creator of a vertex stores its index there (k_emit_points) and only
+// corners of emitted quads -- which are always vertices -- are ever read (k_emit_cells).
+__device__ __forceinline__ size_t corner_map_index(const Grid &g, int cx, int cy, int cz) {
+  return ((size_t)cz * (g.ny + 1) + cy) * (size_t)(g.nx + 1) + cx;
+}
 
 __device__ __forceinline__ size_t word_index(const Grid &g, int y, int z, int k) {
   return ((size_t)(z - g.cz0) * g.ny + y) * g.W + k;
@@ -444,6 +453,7 @@ __global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo
   corner_point(geo, (long long)k * 64 + lo + (e & 1), y + ((e >> 1) & 1), g.zglob0 + z + (e >> 2), p);
   float *dst = a.points + 3 * v;                 // ghost points first, owned points from 3*V0 on
   dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+  if (a.cmap) a.cmap[corner_map_index(g, k * 64 + lo + (e & 1), y + ((e >> 1) & 1), z + (e >> 2))] = (u32)v;
 }
 
 // the six face masks of a word only (7 bit-rows instead of 27)
@@ -458,8 +468,10 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
   F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
 }
 
-// K3b: one lane per quad of the owned range.
-__global__ __launch_bounds__(256) void k_emit_quads(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
+// K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
+// (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nQ) return;
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(256) void k_emit_quads(EmitArgs a, Grid g, size_t n
   const int f = select_bit8(fm, (int)r - before);
   const int x = k * 64 + lo;
   const int zp = a.alias[z];
-  u64 ids[4];
+  u64 lid[4];                                    // vertex index in the counted range
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int i = kFaceCorner[f][c];
@@ -506,10 +518,35 @@ __global__ __launch_bounds__(256) void k_emit_quads(EmitArgs a, Grid g, size_t n
       }
       if (hit) cz = zp + 1;
     }
-    ids[c] = corner_id_generic(a, g, cx, cy, cz) - V0 + a.pointOffset;
+    lid[c] = a.cmap ? (u64)a.cmap[corner_map_index(g, cx, cy, cz)] : corner_id_generic(a, g, cx, cy, cz);
   }
-  u64 *dst = a.cells + 4 * q;
-  dst[0] = ids[0]; dst[1] = ids[1]; dst[2] = ids[2]; dst[3] = ids[3];
+  u64 id[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) id[c] = lid[c] - V0 + a.pointOffset;
+  if (!TRI) {
+    u64 *dst = a.cells + 4 * q;
+    dst[0] = id[0]; dst[1] = id[1]; dst[2] = id[2]; dst[3] = id[3];
+  } else {
+    float v[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float *p = a.points + 3 * lid[c];
+      v[c][0] = p[0]; v[c][1] = p[1]; v[c][2] = p[2];
+    }
+    double d02 = 0.0, d13 = 0.0;                                              // I10
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const double d = (double)v[2][t] - (double)v[0][t]; d02 += d * d; }
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const double d = (double)v[3][t] - (double)v[1][t]; d13 += d * d; }
+    u64 *o = a.cells + 6 * q;
+    if (d02 >= d13) {                                                         // txx:298-302
+      o[0] = id[0]; o[1] = id[1]; o[2] = id[3];
+      o[3] = id[1]; o[4] = id[2]; o[5] = id[3];
+    } else {                                                                  // txx:303-307
+      o[0] = id[0]; o[1] = id[1]; o[2] = id[2];
+      o[3] = id[0]; o[4] = id[2]; o[5] = id[3];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,13 +558,15 @@ template <class T>
 struct Sampler {
   const T *vox;
   int nx, ny, nzb;
-  long long zglob0, gnz;
-  __device__ __forceinline__ T at(long long x, long long y, long long zg) const {   // global z in, clamped
-    long long z = zg - zglob0;
-    z = z < 0 ? 0 : (z > nzb - 1 ? nzb - 1 : z);
-    return vox[((size_t)z * ny + y) * nx + x];
+  int zglob0, gnz;
+  __device__ __forceinline__ int zlocal(int zg) const {          // global z -> buffer slice
+    const int z = zg - zglob0;
+    return z < 0 ? 0 : (z > nzb - 1 ? nzb - 1 : z);
   }
-  __device__ __forceinline__ T at_clamped(long long x, long long y, long long zg) const {
+  __device__ __forceinline__ T at(int x, int y, int zg) const {   // global z in
+    return vox[((size_t)zlocal(zg) * ny + y) * nx + x];
+  }
+  __device__ __forceinline__ T at_clamped(int x, int y, int zg) const {
     x = x < 0 ? 0 : (x > nx - 1 ? nx - 1 : x);
     y = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     zg = zg < 0 ? 0 : (zg > gnz - 1 ? gnz - 1 : zg);
@@ -535,18 +574,18 @@ struct Sampler {
   }
 };
 
-__device__ __forceinline__ long long to_index_clamped(double b, long long end) {
+__device__ __forceinline__ int to_index_clamped(double b, int end) {
   if (!(b >= 0.0)) return 0;            // also NaN (quirk Q4): never read out of bounds
   if (b >= (double)end) return end;
-  return (long long)b;
+  return (int)b;
 }
 
 struct Cell8 {
-  long long lo[3], hi[3];
+  int lo[3], hi[3];
   double d[3];
 };
 
-__device__ __forceinline__ void make_cell(const Geo &geo, const long long n[3], const double p[3], Cell8 &c) {
+__device__ __forceinline__ void make_cell(const Geo &geo, const int n[3], const double p[3], Cell8 &c) {
   double cv[3], ci[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) cv[k] = p[k] - geo.origin[k];                // I4
@@ -569,20 +608,16 @@ __device__ __forceinline__ void make_cell(const Geo &geo, const long long n[3], 
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
 // I6: GradientImageFilter at one pixel
-template <class T>
-__device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo, bool dirIdentity, long long x, long long y,
-                                            long long z, float f0, float out[3]) {
+__device__ __forceinline__ void gradient_from_taps(const Geo &geo, bool dirIdentity, const float fm[3], float f0,
+                                                   const float fp[3], float out[3]) {
   float local[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const float c = geo.gcoef[a];
-    const long long dx = (a == 0), dy = (a == 1), dz = (a == 2);
-    const float fm = (float)s.at_clamped(x - dx, y - dy, z - dz);
-    const float fp = (float)s.at_clamped(x + dx, y + dy, z + dz);
     float sum = 0.0f;
-    sum += (-c) * fm;
+    sum += (-c) * fm[a];
     sum += 0.0f * f0;
-    sum += c * fp;
+    sum += c * fp[a];
     local[a] = sum;
   }
   if (dirIdentity && finite_f(local[0]) && finite_f(local[1]) && finite_f(local[2])) {
@@ -601,43 +636,128 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
   }
 }
 
-// One lane per vertex.  The eight lattice-site gradients and pixel values of the cell the vertex
-// sits in are kept in registers and only re-gathered when the walk enters another cell (steps are
-// <= a quarter voxel and shrink, so most iterations re-use them): the per-iteration work is then
-// the trilinear weights, 32 multiply-adds, one sqrt and three divides, all in f64.
+template <class T>
+__device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo, bool dirIdentity, int x, int y, int z,
+                                            float f0, float out[3]) {
+  float fm[3], fp[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const int dx = (a == 0), dy = (a == 1), dz = (a == 2);
+    fm[a] = (float)s.at_clamped(x - dx, y - dy, z - dz);
+    fp[a] = (float)s.at_clamped(x + dx, y + dy, z + dz);
+  }
+  gradient_from_taps(geo, dirIdentity, fm, f0, fp, out);
+}
+
+// Gather of the cell around a vertex: the eight lattice-site pixel values and gradients.  When the
+// cell lies inside the image (lo+1 == hi on every axis) the 56 taps are 32 distinct pixels: all 32
+// loads are issued back to back (one memory latency per gather) from 12 row segments.
+template <class T>
+__device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo, bool dirIdentity, const Cell8 &c,
+                                            float G[8][3], double Vd[8]) {
+  if (c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2]) {
+    int xs[4], ys[4], zs[4];
+    xs[0] = c.lo[0] > 0 ? c.lo[0] - 1 : 0;  xs[1] = c.lo[0];  xs[2] = c.hi[0];  xs[3] = c.hi[0] < s.nx - 1 ? c.hi[0] + 1 : s.nx - 1;
+    ys[0] = c.lo[1] > 0 ? c.lo[1] - 1 : 0;  ys[1] = c.lo[1];  ys[2] = c.hi[1];  ys[3] = c.hi[1] < s.ny - 1 ? c.hi[1] + 1 : s.ny - 1;
+    zs[0] = s.zlocal(c.lo[2] > 0 ? c.lo[2] - 1 : 0);  zs[1] = s.zlocal(c.lo[2]);  zs[2] = s.zlocal(c.hi[2]);
+    zs[3] = s.zlocal(c.hi[2] < s.gnz - 1 ? c.hi[2] + 1 : s.gnz - 1);
+    T V[4][4][4];      // [z][y][x]; only the 32 entries below are ever touched
+#pragma unroll
+    for (int zi = 0; zi < 4; zi++)
+#pragma unroll
+      for (int yi = 0; yi < 4; yi++) {
+        const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2);
+        if (!zin && !yin) continue;
+        const T *row = s.vox + ((size_t)zs[zi] * s.ny + ys[yi]) * s.nx;
+        if (zin && yin) {
+#pragma unroll
+          for (int xi = 0; xi < 4; xi++) V[zi][yi][xi] = row[xs[xi]];
+        } else {
+          V[zi][yi][1] = row[xs[1]];
+          V[zi][yi][2] = row[xs[2]];
+        }
+      }
+#pragma unroll
+    for (int counter = 0; counter < 8; counter++) {
+      const int a = (counter & 1) + 1, b = ((counter >> 1) & 1) + 1, cz = (counter >> 2) + 1;
+      const T pix = V[cz][b][a];
+      const float fm[3] = {(float)V[cz][b][a - 1], (float)V[cz][b - 1][a], (float)V[cz - 1][b][a]};
+      const float fp[3] = {(float)V[cz][b][a + 1], (float)V[cz][b + 1][a], (float)V[cz + 1][b][a]};
+      Vd[counter] = (double)pix;
+      gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
+    }
+  } else {
+    // vertex on or beyond the image border: clamped neighbours, generic taps
+#pragma unroll
+    for (int counter = 0; counter < 8; counter++) {
+      const int nx_ = (counter & 1) ? c.hi[0] : c.lo[0];
+      const int ny_ = (counter & 2) ? c.hi[1] : c.lo[1];
+      const int nz_ = (counter & 4) ? c.hi[2] : c.lo[2];
+      const T pix = s.at(nx_, ny_, nz_);
+      Vd[counter] = (double)pix;
+      gradient_at(s, geo, dirIdentity, nx_, ny_, nz_, (float)pix, G[counter]);
+    }
+  }
+}
+
+// The walk takes 1..max_steps+2 iterations per vertex, so a plain lane-per-vertex launch idles
+// most lanes behind the slowest vertex of each wave.  Here every wave owns a contiguous chunk of
+// vertices and REFILLS lanes whose vertex has converged (when at least REFILL lanes are idle),
+// so the f64-bound loop body runs with nearly full waves until the chunk is drained.
+// The eight lattice-site gradients and pixel values of the cell a vertex sits in are kept in
+// registers and only re-gathered when the walk enters another cell (steps are <= a quarter voxel
+// and shrink): the per-iteration work is then the trilinear weights, 32 multiply-adds, one sqrt
+// and three divides, all in f64 in the reference's operation order.
 template <class T>
 __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
-                                                 float *__restrict__ points, u64 nPoints, u64 nGhost,
-                                                 Totals *__restrict__ tot) {
-  const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+                                                 float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
+                                                 int REFILL, Totals *__restrict__ tot) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  u64 next = wave * chunk;                        // wave-uniform cursor into this wave's chunk
+  u64 end = next + chunk;
+  if (end > nPoints) end = nPoints;
+  if (next >= end) return;
+  Sampler<T> s{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
+  const int n[3] = {g.nx, g.ny, (int)g.gnz};
+  const double iso = (double)(T)prm.iso;
   unsigned myIters = 0;
-  if (v < nPoints) {
-    Sampler<T> s{vox, g.nx, g.ny, g.nzb, g.zglob0, g.gnz};
-    const long long n[3] = {g.nx, g.ny, g.gnz};
-    const double iso = (double)(T)prm.iso;
-    float vertex[3] = {points[3 * v], points[3 * v + 1], points[3 * v + 2]};
-    bool done = false;
-    double step = prm.step;
-    unsigned numberOfSteps = 0;
-    long long kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};     // cell held in registers
-    float G[8][3];
-    double Vd[8];
-    while (!done) {
-      myIters++;
+  bool active = false;
+  u64 idx = 0;
+  float vertex[3] = {0.f, 0.f, 0.f};
+  double step = 0.0;
+  unsigned numberOfSteps = 0;
+  int kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};           // cell held in registers
+  float G[8][3];
+  double Vd[8];
+  for (;;) {
+    const u64 idle = __ballot(!active);
+    if (idle && next < end && (__popcll(idle) >= REFILL || idle == ~0ull)) {
+      const u64 remaining = end - next;
+      if (!active) {
+        const u64 rank = (u64)__popcll(idle & lowmask(lane));
+        if (rank < remaining) {
+          idx = next + rank;
+          vertex[0] = points[3 * idx]; vertex[1] = points[3 * idx + 1]; vertex[2] = points[3 * idx + 2];
+          step = prm.step;
+          numberOfSteps = 0;
+          kl[0] = -1;
+          active = true;
+        }
+      }
+      const u64 take = (u64)__popcll(idle);
+      next += take < remaining ? take : remaining;
+    }
+    if (!__ballot(active)) break;
+    if (active) {
+      if (idx >= nGhost) myIters++;
+      bool done = false;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
       make_cell(geo, n, p, c);
       if (c.lo[0] != kl[0] || c.lo[1] != kl[1] || c.lo[2] != kl[2] || c.hi[0] != kh[0] || c.hi[1] != kh[1] ||
           c.hi[2] != kh[2]) {
-#pragma unroll
-        for (unsigned counter = 0; counter < 8; counter++) {
-          const long long nx_ = (counter & 1u) ? c.hi[0] : c.lo[0];
-          const long long ny_ = (counter & 2u) ? c.hi[1] : c.lo[1];
-          const long long nz_ = (counter & 4u) ? c.hi[2] : c.lo[2];
-          const T pix = s.at(nx_, ny_, nz_);
-          Vd[counter] = (double)pix;
-          gradient_at(s, geo, dirIdentity != 0, nx_, ny_, nz_, (float)pix, G[counter]);
-        }
+        gather_cell(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
         for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
       }
@@ -655,61 +775,34 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
           total += overlap;
         }
       }
-      float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
-      double sq = 0.0;                                                        // I8 (txx:452)
+      done = fabs(value - iso) < prm.thr;                                     // txx:456
+      if (!done) {
+        // (the reference normalises before the test, txx:452; the normal is only used when stepping)
+        float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
+        double sq = 0.0;                                                      // I8
 #pragma unroll
-      for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
-      const double norm = sqrt(sq);
+        for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
+        const double norm = sqrt(sq);
 #pragma unroll
-      for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
-      done |= fabs(value - iso) < prm.thr;                                    // txx:456
-      if (done) break;
-      const double sign = (value < iso) ? +1.0 : -1.0;                        // txx:463
+        for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+        const double sign = (value < iso) ? +1.0 : -1.0;                      // txx:463
 #pragma unroll
-      for (int k = 0; k < 3; k++)                                             // txx:464-467 (I9)
-        vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
-      step *= prm.relax;                                                      // txx:468
-      done |= numberOfSteps++ > prm.max_steps;                                // txx:469
+        for (int k = 0; k < 3; k++)                                           // txx:464-467 (I9)
+          vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
+        step *= prm.relax;                                                    // txx:468
+        done = numberOfSteps++ > prm.max_steps;                               // txx:469
+      }
+      if (done) {
+        points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
+        active = false;
+      }
     }
-    points[3 * v] = vertex[0]; points[3 * v + 1] = vertex[1]; points[3 * v + 2] = vertex[2];
-    if (v < nGhost) myIters = 0;
   }
   // one atomic per wave for the iteration statistic
   unsigned sum = myIters;
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
-  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K5: triangulate (txx:286-321): split along the shorter diagonal of the projected quad.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_triangulate(const u64 *__restrict__ quads, const float *__restrict__ points,
-                                                     u64 *__restrict__ tris, u64 nQuads, u64 pointOffset,
-                                                     u64 nGhost) {
-  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nQuads) return;
-  u64 f[4];
-  float v[4][3];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    f[i] = quads[4 * q + i];
-    const float *p = points + 3 * (f[i] - pointOffset + nGhost);   // ghost ids are offset-ghost..offset-1
-    v[i][0] = p[0]; v[i][1] = p[1]; v[i][2] = p[2];
-  }
-  double d02 = 0.0, d13 = 0.0;                                                // I10
-#pragma unroll
-  for (int k = 0; k < 3; k++) { const double d = (double)v[2][k] - (double)v[0][k]; d02 += d * d; }
-#pragma unroll
-  for (int k = 0; k < 3; k++) { const double d = (double)v[3][k] - (double)v[1][k]; d13 += d * d; }
-  u64 *o = tris + 6 * q;
-  if (d02 >= d13) {                                                           // txx:298-302
-    o[0] = f[0]; o[1] = f[1]; o[2] = f[3];
-    o[3] = f[1]; o[4] = f[2]; o[5] = f[3];
-  } else {                                                                    // txx:303-307
-    o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
-    o[3] = f[0]; o[4] = f[2]; o[5] = f[3];
-  }
+  if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -768,7 +861,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
 }
 
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s) {
-  hipLaunchKernelGGL(k_alias, dim3(1), dim3(64), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
+  hipLaunchKernelGGL(k_alias, dim3((g.nzb + 255) / 256), dim3(256), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
   return hipGetLastError();
 }
 
@@ -794,18 +887,32 @@ hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hip
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const Workspace &w, const Grid &g, const Geo &geo, int triangles, u64 pointOffset, u64 nV, u64 nQ,
-                       hipStream_t s) {
+static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
   EmitArgs a;
   a.bits = w.bits; a.alias = w.alias; a.prefix = w.prefix;
   a.segBaseV = w.segBaseV; a.segBaseQ = w.segBaseQ; a.tot = w.totals;
   a.points = w.points;
-  a.cells = triangles ? w.quads : w.cells;
+  a.cells = w.cells;
   a.pointOffset = pointOffset;
+  a.cmap = w.cmap;
+  return a;
+}
+
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s) {
+  if (!nV) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   const size_t nseg = (nwords + 63) >> 6;
-  if (nV) hipLaunchKernelGGL(k_emit_points, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, a, g, geo, nseg, nwords, nV);
-  if (nQ) hipLaunchKernelGGL(k_emit_quads, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
+  hipLaunchKernelGGL(k_emit_points, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo, nseg, nwords, nV);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s) {
+  if (!nQ) return hipSuccess;
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const size_t nseg = (nwords + 63) >> 6;
+  const EmitArgs a = emit_args(w, pointOffset);
+  if (triangles) hipLaunchKernelGGL(k_emit_cells<true>, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
+  else hipLaunchKernelGGL(k_emit_cells<false>, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
   return hipGetLastError();
 }
 
@@ -814,20 +921,20 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
+  // contiguous chunk of vertices per wave: about 12 waves' worth per SIMD keeps the tail short
+  u64 chunk = (nPoints + 12287) / 12288;
+  chunk = (chunk + 63) / 64 * 64;
+  if (chunk < 256) chunk = 256;
+  const u64 nwaves = (nPoints + chunk - 1) / chunk;
+  int refill = 16;
+  if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
-    const unsigned blocks = grid_for(nPoints, 256, 0);
+    const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
-                       nPoints, nGhost, w.totals);
+                       nPoints, nGhost, chunk, refill, w.totals);
     return hipGetLastError();
   });
-}
-
-hipError_t launch_triangulate(const Workspace &w, u64 nQuads, u64 pointOffset, u64 nGhost, hipStream_t s) {
-  if (nQuads == 0) return hipSuccess;
-  const unsigned blocks = grid_for(nQuads, 256, 0);
-  hipLaunchKernelGGL(k_triangulate, dim3(blocks), dim3(256), 0, s, w.quads, w.points, w.cells, nQuads, pointOffset, nGhost);
-  return hipGetLastError();
 }
 
 }  // namespace cuberille
