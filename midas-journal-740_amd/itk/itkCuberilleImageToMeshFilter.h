@@ -1,0 +1,161 @@
+// itkCuberilleImageToMeshFilter.h -- MI355X drop-in for the filter of midas-journal-740.
+//
+// Same class name, namespace, template parameters (and default), base class and public surface
+// as /root/reference/Source/itkCuberilleImageToMeshFilter.h:110-236, so that the reference's
+// Testing/CuberilleTest01.cxx and Source/examples.cxx compile against it unchanged.  Nothing of
+// the reference's CPU algorithm lives here: GenerateData() (implementation file) marshals the
+// image and the eight parameters into the C ABI of include/cuberille_hip.h, the HIP kernels in
+// libcuberille_hip.so do the work on the GPU, and the flat buffers that come back are poured into
+// the itk::Mesh with ITK's own ownership rules.  Builds against real ITK 3.x/4.x headers, or
+// against the ITK-lite headers in itk_lite/ when ITK is not installed.
+#ifndef __itkCuberilleImageToMeshFilter_h
+#define __itkCuberilleImageToMeshFilter_h
+
+#include "itkMacro.h"
+#include "itkMesh.h"
+#include "itkImageToMeshFilter.h"
+#include "itkCellInterface.h"
+#include "itkTriangleCell.h"
+#include "itkQuadrilateralCell.h"
+#include "itkDefaultStaticMeshTraits.h"
+#include "itkConstShapedNeighborhoodIterator.h"
+#include "itkLinearInterpolateImageFunction.h"
+#include "itkGradientImageFilter.h"
+#include "itkVectorLinearInterpolateImageFunction.h"
+#include "itkNumericTraits.h"
+
+struct cuberille_ctx;   // include/cuberille_hip.h
+
+namespace itk
+{
+
+template <class TInputImage, class TOutputMesh,
+          class TInterpolator = itk::LinearInterpolateImageFunction<TInputImage> >
+class ITK_EXPORT CuberilleImageToMeshFilter : public ImageToMeshFilter<TInputImage, TOutputMesh>
+{
+public:
+  typedef CuberilleImageToMeshFilter                  Self;
+  typedef ImageToMeshFilter<TInputImage, TOutputMesh> Superclass;
+  typedef SmartPointer<Self>                          Pointer;
+  typedef SmartPointer<const Self>                    ConstPointer;
+
+  itkNewMacro(Self);
+  itkTypeMacro(CuberilleImageToMeshFilter, ImageToMeshFilter);
+
+  // -- output side (reference h:127-145) --
+  typedef TOutputMesh                                      OutputMeshType;
+  typedef typename OutputMeshType::Pointer                 OutputMeshPointer;
+  typedef typename OutputMeshType::MeshTraits              OutputMeshTraits;
+  typedef typename OutputMeshType::PointType               OutputPointType;
+  typedef typename OutputMeshType::PointType               PointType;
+  typedef typename OutputMeshTraits::PixelType             OutputPixelType;
+  typedef typename OutputMeshType::CellTraits              CellTraits;
+  typedef typename OutputMeshType::PointsContainer         PointsContainer;
+  typedef typename OutputMeshType::PointsContainerPointer  PointsContainerPointer;
+  typedef typename OutputMeshType::CellsContainer          CellsContainer;
+  typedef typename OutputMeshType::CellsContainerPointer   CellsContainerPointer;
+  typedef typename OutputMeshType::PointIdentifier         PointIdentifier;
+  typedef typename OutputMeshType::CellIdentifier          CellIdentifier;
+  typedef CellInterface<OutputPixelType, CellTraits>       CellInterfaceType;
+  typedef TriangleCell<CellInterfaceType>                  TriangleCellType;
+  typedef typename TriangleCellType::SelfAutoPointer       TriangleAutoPointer;
+  typedef typename TriangleCellType::CellAutoPointer       TriangleCellAutoPointer;
+  typedef QuadrilateralCell<CellInterfaceType>             QuadrilateralCellType;
+  typedef typename QuadrilateralCellType::SelfAutoPointer  QuadrilateralAutoPointer;
+  typedef typename QuadrilateralCellType::CellAutoPointer  QuadrilateralCellAutoPointer;
+
+  // -- input side (reference h:147-159) --
+  typedef TInputImage                               InputImageType;
+  typedef typename InputImageType::Pointer          InputImagePointer;
+  typedef typename InputImageType::ConstPointer     InputImageConstPointer;
+  typedef typename InputImageType::PixelType        InputPixelType;
+  typedef typename InputImageType::SizeType         SizeType;
+  typedef typename InputImageType::SpacingType      SpacingType;
+  typedef typename InputImageType::SpacingValueType SpacingValueType;
+  typedef typename InputImageType::IndexType        IndexType;
+  typedef TInterpolator                             InterpolatorType;
+  typedef typename InterpolatorType::Pointer        InterpolatorPointer;
+  typedef typename InterpolatorType::OutputType     InterpolatorOutputType;
+
+  // -- names the reference exposes for its CPU internals (h:162-173); kept so user code that
+  //    mentions them still compiles, unused by the GPU path --
+  typedef ConstShapedNeighborhoodIterator<InputImageType>              InputImageIteratorType;
+  typedef GradientImageFilter<InputImageType>                          GradientFilterType;
+  typedef typename GradientFilterType::Pointer                         GradientFilterPointer;
+  typedef typename GradientFilterType::OutputImageType                 GradientImageType;
+  typedef typename GradientImageType::Pointer                          GradientImagePointer;
+  typedef typename GradientFilterType::OutputPixelType                 GradientPixelType;
+  typedef itk::VectorLinearInterpolateImageFunction<GradientImageType> GradientInterpolatorType;
+  typedef typename GradientInterpolatorType::Pointer                   GradientInterpolatorPointer;
+
+  /** Iso-surface value: pixels >= this value are inside (reference h:180-181, txx:139-141). */
+  itkGetMacro(IsoSurfaceValue, InputPixelType);
+  itkSetMacro(IsoSurfaceValue, InputPixelType);
+
+  /** The image to polygonize (reference h:184, txx:53-56). */
+  virtual void SetInput(const InputImageType *inputImage);
+
+  /** Interpolator (reference h:187-188).  The GPU path implements
+   *  LinearInterpolateImageFunction<TInputImage,double>; any other type makes Update() throw. */
+  itkGetObjectMacro(Interpolator, InterpolatorType);
+  itkSetObjectMacro(Interpolator, InterpolatorType);
+
+  /** Triangles (true, default) or quadrilaterals (reference h:193-195). */
+  itkGetMacro(GenerateTriangleFaces, bool);
+  itkSetMacro(GenerateTriangleFaces, bool);
+  itkBooleanMacro(GenerateTriangleFaces);
+
+  /** Project vertices onto the iso-surface (default true; reference h:199-201). */
+  itkGetMacro(ProjectVerticesToIsoSurface, bool);
+  itkSetMacro(ProjectVerticesToIsoSurface, bool);
+  itkBooleanMacro(ProjectVerticesToIsoSurface);
+
+  /** Projection knobs with the reference's clamps (h:209-228); defaults 0.5, max spacing / 4, 0.95, 50. */
+  itkGetMacro(ProjectVertexSurfaceDistanceThreshold, double);
+  itkSetClampMacro(ProjectVertexSurfaceDistanceThreshold, double, 0.0, NumericTraits<InputPixelType>::max());
+  itkGetMacro(ProjectVertexStepLength, double);
+  itkSetClampMacro(ProjectVertexStepLength, double, 0.0, 100000.0);
+  itkGetMacro(ProjectVertexStepLengthRelaxationFactor, double);
+  itkSetClampMacro(ProjectVertexStepLengthRelaxationFactor, double, 0.0, 1.0);
+  itkGetMacro(ProjectVertexMaximumNumberOfSteps, unsigned int);
+  itkSetMacro(ProjectVertexMaximumNumberOfSteps, unsigned int);
+
+  /** Not in the reference: GPU device to run on (default 0), and the device time in seconds of
+   *  the last GenerateData() (all kernels, excluding the PCIe copies and the itk::Mesh fill). */
+  itkGetMacro(Device, int);
+  itkSetMacro(Device, int);
+  itkGetMacro(LastDeviceSeconds, double);
+
+protected:
+  CuberilleImageToMeshFilter();
+  ~CuberilleImageToMeshFilter();
+  void PrintSelf(std::ostream &os, Indent indent) const;
+
+  void GenerateData();
+  virtual void GenerateOutputInformation() {}   // as the reference (h:236)
+
+private:
+  CuberilleImageToMeshFilter(const Self &);   // not implemented
+  void operator=(const Self &);               // not implemented
+
+  InputPixelType      m_IsoSurfaceValue;
+  InterpolatorPointer m_Interpolator;
+  SpacingValueType    m_MaxSpacing;
+  bool                m_GenerateTriangleFaces;
+  bool                m_ProjectVerticesToIsoSurface;
+  double              m_ProjectVertexSurfaceDistanceThreshold;
+  double              m_ProjectVertexStepLength;
+  double              m_ProjectVertexStepLengthRelaxationFactor;
+  unsigned int        m_ProjectVertexMaximumNumberOfSteps;
+  int                 m_Device;
+  double              m_LastDeviceSeconds;
+  ::cuberille_ctx    *m_Context;
+};
+
+} // end namespace itk
+
+#ifndef ITK_MANUAL_INSTANTIATION
+#include "itkCuberilleImageToMeshFilter.txx"
+#endif
+
+#endif

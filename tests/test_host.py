@@ -123,3 +123,26 @@ def test_volume_generators_numpy_vs_torch(pkg):
     assert np.array_equal(whole, parts)
     stacked = vol.marschner_lobb(16, 0, 32, period=16)
     assert np.allclose(stacked[:16], stacked[16:]) and np.allclose(stacked[:16], vol.marschner_lobb(16))
+
+
+def test_dropin_header_compiles_the_unchanged_reference_driver(pkg):
+    """Where the reference tree is present (the build container), CuberilleTest01.cxx and examples.cxx
+    compile unchanged against itk/itkCuberilleImageToMeshFilter.h; without a GPU the binary fails the
+    reference's way: itk::ExceptionObject caught, EXIT_FAILURE (CuberilleTest01.cxx:207-212)."""
+    import subprocess
+    ref = "/root/reference/Testing/CuberilleTest01.cxx"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this machine")
+    pkg._abi.build()
+    itk_dir = os.path.join(ROOT, "midas-journal-740_amd", "itk")
+    subprocess.check_call(["make", "-s", "-C", itk_dir])
+    exe = os.path.join(itk_dir, "build", "CuberilleTest01")
+    assert os.path.exists(exe) and os.path.exists(os.path.join(itk_dir, "build", "Examples"))
+    # the reference's own filter sources must not have been compiled in
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "cuberille_extract_host" in syms
+    if _has_gpu(pkg):
+        return
+    r = subprocess.run([exe, "Test01", os.path.join(ROOT, "tests", "golden", "data", "blob0.mha"), "/tmp/_blob0.vtk", "200",
+                        "8", "6", "0", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "ExceptionObject caught" in r.stderr and "no CPU fallback" in r.stderr
