@@ -56,6 +56,30 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(args, world, alg_bytes):
+    """HBM bytes per classify launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.csv:
+    FETCH_SIZE and WRITE_SIZE in KiB, collected in separate runs; on gfx950 FETCH_SIZE counts half the
+    bytes of a 16 B/lane coalesced stream, so it is doubled -- MI355X_MICROARCH.md, HBM section).
+    Only valid for the configuration the profile was taken on; otherwise null."""
+    if world != 1 or args.size != 1024 or args.workload != "marschner_lobb":
+        return None, None
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for row in csv.DictReader(open(files[-1])):
+        if "k_classify_flat<float" in row["kernel"]:
+            if row["counter"] == "FETCH_SIZE":
+                fetch = float(row["mean_value_KB"])
+            if row["counter"] == "WRITE_SIZE":
+                write = float(row["mean_value_KB"])
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(pkg, torch, args, device):
     """The oracle restatement of the reference ("port"), timed on this box's host cores on a
     bounded sample of the same workload (the reference itself needs ITK)."""
@@ -161,6 +185,7 @@ def main():
         alg_bytes = float(n) * n * (sh.hi - sh.lo) * np.dtype(dtype).itemsize     # what one classify launch reads
         classify_gbs = alg_bytes / (stages["ms_classify"] * 1e-3) / 1e9
         pass_ms = stages["ms_classify"] + stages["ms_count"] + stages["ms_scan"]
+        traffic, traffic_src = measured_traffic(args, world, alg_bytes)
         out = {
             "metric": "Mvoxels/s polygonized + achieved HBM GB/s, 1024^3 float32 @1/2/4/8 GPU",
             "value": round(voxels * args.steps / dt / 1e6, 1),
@@ -180,8 +205,8 @@ def main():
                        "projection_iterations_rank0": int(res.proj_iterations)},
             "roofline": {"bound": "hbm", "kernel": "k_classify_flat (threshold + bit-pack sweep)",
                          "achieved": round(classify_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(classify_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes": alg_bytes,
+                         "frac": round(classify_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                          "classify_count_scan_pass": {"ms": round(pass_ms, 4),
                                                       "achieved": round(alg_bytes / (pass_ms * 1e-3) / 1e9, 1),
                                                       "frac": round(alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
