@@ -96,10 +96,10 @@ def cpu_baseline(pkg, torch, args, device):
     secs = m.info["seconds_gradient"] + m.info["seconds_sweep"]
     return {
         "value": round(n ** 3 / secs / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-        "sample": "%s %d^3 %s (same generator and parameters as the GPU workload, 1/%d of its voxels); "
+        "sample": "%s %d^3 %s (same generator and parameters as the GPU workload, %.3g x fewer voxels); "
                   "sweep single-threaded like the reference, gradient pre-pass on %d threads like ITK; "
                   "%.1f s gradient + %.1f s sweep, %d points / %d cells; wall %.1f s" % (
-                      args.workload, n, np.dtype(dtype).name, max(1, (args.size // n) ** 3), cores,
+                      args.workload, n, np.dtype(dtype).name, (args.size / float(n)) ** 3, cores,
                       m.info["seconds_gradient"], m.info["seconds_sweep"], len(m.points), len(m.cells), dt),
     }
 
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--workload", default="marschner_lobb", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the cube the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the cube the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-project", action="store_true")
     ap.add_argument("--thr", type=float, default=None, help="override the projection threshold (experiments)")
     args = ap.parse_args()

@@ -42,7 +42,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap;
+  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   // state of the last count
@@ -167,7 +167,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->occ, &c->alias, &c->prefix, &c->segV, &c->segQ, &c->segBaseV,
-                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap};
+                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -313,8 +313,16 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
     if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
     else (void)hipGetLastError();
   }
+  // head tables for the per-wave inverse mapping (4 B per 64 outputs)
+  w.headV = w.headQ = nullptr;
+  if (c->nwords < 0xffffffffULL && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess &&
+      c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) {
+    w.headV = (u32 *)c->headV.p;
+    w.headQ = (u32 *)c->headQ.p;
+  }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
+  HIP_TRY(c, launch_heads(w, c->nwords, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));

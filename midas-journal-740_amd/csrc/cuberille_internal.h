@@ -59,6 +59,7 @@ struct Workspace {     // device pointers valid for one count/emit pair
   float *points;
   u64 *cells;
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
+  u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
 };
 
 struct Params {
@@ -72,6 +73,7 @@ struct Params {
 hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, hipStream_t s);
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s);
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
+hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s);
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s);

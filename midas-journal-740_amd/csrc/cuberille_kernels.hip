@@ -44,8 +44,6 @@ __device__ __constant__ const int kEncCorner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
 // face -> its four corners in the order of txx:197-202
 __device__ __constant__ const int kFaceCorner[6][4] = {{0, 4, 7, 3}, {0, 1, 5, 4}, {1, 2, 6, 5},
                                                        {2, 3, 7, 6}, {0, 3, 2, 1}, {4, 5, 6, 7}};
-// face -> 8-bit mask of its corners (txx:226-231)
-__device__ __constant__ const unsigned kFaceCornerMask[6] = {0x99, 0x33, 0x66, 0xCC, 0x0F, 0xF0};
 
 // ---------------------------------------------------------------------------------------------
 // K1: classify (threshold + bit-pack).  inside(u) := !(pixel(u) < iso)   (txx:139-141,167)
@@ -322,6 +320,7 @@ struct EmitArgs {
   u64 *cells;          // 4 ids per quad, or 2 x 3 ids per quad when triangulating
   u64 pointOffset;     // global id of this rank's first point
   u32 *cmap;           // dense lattice-corner -> vertex index map, or null (see corner_map_index)
+  const u32 *headV, *headQ;   // word producing output 64*i (k_heads), or null
 };
 
 // The reference finds a corner's id in a std::map keyed by (x,y) per z-plane (h:272-313).  With
@@ -388,12 +387,162 @@ __device__ u64 corner_id_generic(const EmitArgs &a, const Grid &g, int cx, int c
   return id;
 }
 
-// Inverse mapping: output index -> source.  Every output (vertex v, quad q) has exactly one
-// producing voxel; ids are positions in the raster-ordered enumeration, so the producer is found
-// by searching the prefix arrays: segment (binary search over the scanned segment bases), word
-// (binary search over the in-segment exclusive prefixes), voxel and corner/face inside the word
-// (popcount prefix over the word's masks).  One lane per OUTPUT keeps every lane busy; the
-// surface is ~1 % of the voxels, so a lane per voxel (or per word) would idle almost all lanes.
+// Inverse mapping: output index -> source.  Every output (vertex, quad) has exactly one producing
+// voxel and its id is its position in the raster-ordered enumeration, so a block that owns a fixed
+// range of 1024 words (16 scan segments) knows the contiguous range of outputs it must write:
+//   1. stage the words' exclusive output prefixes in LDS (block-relative),
+//   2. compact the non-empty words (block scan), classify them once each -- one lane per non-empty
+//      word, 256 per round -- and park their bit masks in LDS,
+//   3. one lane per OUTPUT: binary search in LDS for its word, popcount-select the voxel and the
+//      corner/face inside the word, write.
+// The surface is ~1 % of the voxels: a lane per voxel (or per word) would idle almost every lane,
+// a lane per output keeps them all busy and writes each output buffer front to back.
+constexpr int EMIT_WB = 1024;       // words per block
+constexpr int EMIT_ROUND = 256;     // non-empty words classified per round (one per thread)
+
+struct EmitBlock {
+  u32 pre[EMIT_WB + 1];
+  unsigned short list[EMIT_WB];
+  int waveTot[4];
+};
+
+template <int SHIFT>
+__device__ __forceinline__ int emit_block_setup(EmitBlock &sb, const u64 *__restrict__ segBase,
+                                                const u32 *__restrict__ prefix, u64 total, size_t nwords, size_t w0,
+                                                u64 &base) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  base = segBase[w0 >> 6];
+  const size_t wEnd = (w0 + EMIT_WB < nwords) ? w0 + EMIT_WB : nwords;
+  const u32 tot = (wEnd < nwords) ? (u32)(segBase[wEnd >> 6] - base) : (u32)(total - base);
+  for (int i = tid; i < EMIT_WB; i += 256) {
+    const size_t gi = w0 + i;
+    sb.pre[i] = gi < nwords ? (u32)(segBase[gi >> 6] - base) + ((prefix[gi] >> SHIFT) & 0xffffu) : tot;
+  }
+  if (tid == 0) sb.pre[EMIT_WB] = tot;
+  __syncthreads();
+  bool ne[4];
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { ne[j] = sb.pre[tid * 4 + j + 1] > sb.pre[tid * 4 + j]; cnt += ne[j] ? 1 : 0; }
+  int incl = cnt;
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
+  if (lane == 63) sb.waveTot[wv] = incl;
+  __syncthreads();
+  int off = 0, n = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) { if (w < wv) off += sb.waveTot[w]; n += sb.waveTot[w]; }
+  int pos = off + incl - cnt;
+#pragma unroll
+  for (int j = 0; j < 4; j++) if (ne[j]) sb.list[pos++] = (unsigned short)(tid * 4 + j);
+  __syncthreads();
+  return n;
+}
+
+// largest j in [lo, hi) with pre[list[j]] <= o
+__device__ __forceinline__ int emit_find_word(const EmitBlock &sb, int lo, int hi, u32 o) {
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sb.pre[sb.list[mid]] <= o) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// position of the set bit of rank r (0-based) in an 8-bit mask
+__device__ __forceinline__ int select_bit8(unsigned m, int r) {
+  for (int i = 0; i < r; i++) m &= m - 1;
+  return __ffs((int)m) - 1;
+}
+
+// K3a: vertices of the counted range (a slab's ghost slice included: the rank above needs those
+// coordinates for the triangle split of its first slice).
+__global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo, size_t nwords) {
+  __shared__ EmitBlock sb;
+  __shared__ u64 masks[8][EMIT_ROUND];
+  const int tid = threadIdx.x;
+  const size_t w0 = (size_t)blockIdx.x * EMIT_WB;
+  u64 base;
+  const int nList = emit_block_setup<0>(sb, a.segBaseV, a.prefix, a.tot->totV, nwords, w0, base);
+  for (int r0 = 0; r0 < nList; r0 += EMIT_ROUND) {
+    const int rEnd = (r0 + EMIT_ROUND < nList) ? r0 + EMIT_ROUND : nList;
+    if (r0 + tid < rEnd) {
+      const size_t gi = w0 + sb.list[r0 + tid];
+      const size_t row = gi / g.W;
+      WordInfo w;
+      classify_word(a.bits, a.alias, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), w);
+#pragma unroll
+      for (int i = 0; i < 8; i++) masks[i][tid] = w.C[i];
+    }
+    __syncthreads();
+    const u32 oEnd = sb.pre[sb.list[rEnd - 1] + 1];
+    for (u32 o = sb.pre[sb.list[r0]] + tid; o < oEnd; o += 256) {
+      const int j = emit_find_word(sb, r0, rEnd, o);
+      const int wi = sb.list[j];
+      const u32 r = o - sb.pre[wi];
+      u64 C[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) C[i] = masks[i][j - r0];
+      int lo = 0, hi = 64;                       // largest bit position with (#created before it) <= r
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) c += popc64(C[i] & lowmask(mid));
+        if ((u32)c <= r) lo = mid; else hi = mid;
+      }
+      int before = 0;
+      unsigned cm = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        before += popc64(C[i] & lowmask(lo));
+        cm |= (unsigned)((C[i] >> lo) & 1ull) << i;
+      }
+      const int e = kCornerEnc[select_bit8(cm, (int)r - before)];
+      const size_t gi = w0 + wi;
+      const size_t row = gi / g.W;
+      const int cx = (int)(gi % g.W) * 64 + lo + (e & 1);
+      const int cy = (int)(row % g.ny) + ((e >> 1) & 1);
+      const int cz = g.cz0 + (int)(row / g.ny) + (e >> 2);
+      const u64 v = base + o;                    // vertex index in the counted range
+      float p[3];
+      corner_point(geo, cx, cy, g.zglob0 + cz, p);
+      float *dst = a.points + 3 * v;             // ghost points first, owned points from 3*V0 on
+      dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+      if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
+    }
+    __syncthreads();
+  }
+}
+
+// Global form of the inverse mapping: one lane per output everywhere (no idle lanes, no block
+// synchronisation).  A wave holds 64 consecutive outputs, which come from a short run of words, so
+// the search is done per wave: `head[o/64]` (built by k_heads after the scan) names the word that
+// produces output o & ~63; the 64 lanes load the absolute prefixes of the 64 words from there on and
+// each lane finds its own word with a 6-step shuffle search -- two dependent memory round trips
+// instead of the 24 of a per-lane binary search over the whole volume.  Outputs that lie beyond the
+// window (sparse surface) slide the window; after a few slides the lane falls back to locate_word.
+__global__ __launch_bounds__(256) void k_heads(const u32 *__restrict__ prefix, const u64 *__restrict__ segV,
+                                               const u64 *__restrict__ segQ, const u64 *__restrict__ segBaseV,
+                                               const u64 *__restrict__ segBaseQ, size_t nwords, u32 *__restrict__ headV,
+                                               u32 *__restrict__ headQ) {
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= nwords) return;
+  const u32 p = prefix[gi];
+  const bool last = ((gi & 63) == 63) || (gi + 1 == nwords);
+  const size_t seg = gi >> 6;
+  const u32 nextV = last ? (u32)segV[seg] : (prefix[gi + 1] & 0xffffu);
+  const u32 nextQ = last ? (u32)segQ[seg] : (prefix[gi + 1] >> 16);
+  const u32 cV = nextV - (p & 0xffffu), cQ = nextQ - (p >> 16);
+  if (cV) {
+    const u64 b = segBaseV[seg] + (p & 0xffffu);
+    for (u64 m = (b + 63) & ~63ull; m < b + cV; m += 64) headV[m >> 6] = (u32)gi;
+  }
+  if (cQ) {
+    const u64 b = segBaseQ[seg] + (p >> 16);
+    for (u64 m = (b + 63) & ~63ull; m < b + cQ; m += 64) headQ[m >> 6] = (u32)gi;
+  }
+}
+
 template <int SHIFT>
 __device__ __forceinline__ size_t locate_word(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
                                               size_t nseg, size_t nwords, u64 idx, u32 &within) {
@@ -413,19 +562,42 @@ __device__ __forceinline__ size_t locate_word(const u64 *__restrict__ segBase, c
   return wlo;
 }
 
-// position of the set bit of rank r (0-based) in an 8-bit mask
-__device__ __forceinline__ int select_bit8(unsigned m, int r) {
-  for (int i = 0; i < r; i++) m &= m - 1;
-  return __ffs((int)m) - 1;
+// All 64 lanes of the wave must call this together (idx = consecutive outputs, `valid` lanes only).
+template <int SHIFT>
+__device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
+                                                   const u32 *__restrict__ head, size_t nseg, size_t nwords, u64 idx,
+                                                   bool valid, u32 &within) {
+  const int lane = threadIdx.x & 63;
+  const u64 first = __shfl(idx, 0, 64);          // lane 0 is always valid; first is a multiple of 64
+  size_t w0 = head[first >> 6];
+  size_t found = 0;
+  bool done = !valid;
+  for (int slide = 0; slide < 4; slide++) {
+    const size_t w = w0 + lane;
+    const u64 A = (w < nwords) ? segBase[w >> 6] + ((prefix[w] >> SHIFT) & 0xffffu) : ~0ull;
+    int lo = 0, hi = 64;                         // largest j with A[j] <= idx
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+      const int mid = (lo + hi) >> 1;
+      const u64 v = __shfl(A, mid, 64);
+      if (v <= idx) lo = mid; else hi = mid;
+    }
+    const u64 Alo = __shfl(A, lo, 64);
+    // inside the window unless the last loaded word is still <= idx (its successor is unknown)
+    if (!done && lo < 63) { found = w0 + lo; within = (u32)(idx - Alo); done = true; }
+    if (!__ballot(!done)) return found;
+    w0 += 63;
+  }
+  if (!done) found = locate_word<SHIFT>(segBase, prefix, nseg, nwords, idx, within);
+  return found;
 }
 
-// K3a: one lane per vertex of the counted range (a slab's ghost slice included: the rank above
-// needs those coordinates for the triangle split of its first slice).
-__global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo, size_t nseg, size_t nwords, u64 nV) {
+// K3a, global form: one lane per vertex, wave-window search.
+__global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Geo geo, size_t nseg, size_t nwords, u64 nV) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 r = 0;
+  const size_t gi = locate_word_wave<0>(a.segBaseV, a.prefix, a.headV, nseg, nwords, v, v < nV, r);
   if (v >= nV) return;
-  u32 r;
-  const size_t gi = locate_word<0>(a.segBaseV, a.prefix, nseg, nwords, v, r);
   const size_t row = gi / g.W;
   const int k = (int)(gi % g.W);
   const int y = (int)(row % g.ny);
@@ -447,13 +619,13 @@ __global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo
     before += popc64(w.C[i] & lowmask(lo));
     cm |= (unsigned)((w.C[i] >> lo) & 1ull) << i;
   }
-  const int i = select_bit8(cm, (int)r - before);
-  const int e = kCornerEnc[i];
+  const int e = kCornerEnc[select_bit8(cm, (int)r - before)];
+  const int cx = k * 64 + lo + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
   float p[3];
-  corner_point(geo, (long long)k * 64 + lo + (e & 1), y + ((e >> 1) & 1), g.zglob0 + z + (e >> 2), p);
-  float *dst = a.points + 3 * v;                 // ghost points first, owned points from 3*V0 on
+  corner_point(geo, cx, cy, g.zglob0 + cz, p);
+  float *dst = a.points + 3 * v;
   dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-  if (a.cmap) a.cmap[corner_map_index(g, k * 64 + lo + (e & 1), y + ((e >> 1) & 1), z + (e >> 2))] = (u32)v;
+  if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
 }
 
 // the six face masks of a word only (7 bit-rows instead of 27)
@@ -468,38 +640,9 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
   F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
 }
 
-// K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
-// (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
+// one quad (or its two triangles): corner ids from the dense map, Q1 redirect, fused diagonal split
 template <bool TRI>
-__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
-  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nQ) return;
-  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
-  u32 r;
-  const size_t gi = locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r);
-  const size_t row = gi / g.W;
-  const int k = (int)(gi % g.W);
-  const int y = (int)(row % g.ny);
-  const int z = g.cz0 + (int)(row / g.ny);
-  u64 F[6];
-  faces_word(a.bits, g, y, z, k, F);
-  int lo = 0, hi = 64;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    int c = 0;
-#pragma unroll
-    for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
-    if ((u32)c <= r) lo = mid; else hi = mid;
-  }
-  int before = 0;
-  unsigned fm = 0;
-#pragma unroll
-  for (int f = 0; f < 6; f++) {
-    before += popc64(F[f] & lowmask(lo));
-    fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
-  }
-  const int f = select_bit8(fm, (int)r - before);
-  const int x = k * 64 + lo;
+__device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 q, u64 V0) {
   const int zp = a.alias[z];
   u64 lid[4];                                    // vertex index in the counted range
 #pragma unroll
@@ -547,6 +690,41 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
       o[3] = id[0]; o[4] = id[2]; o[5] = id[3];
     }
   }
+}
+
+// K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
+// (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
+  u32 r = 0;
+  size_t gi;
+  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a.segBaseQ, a.prefix, a.headQ, nseg, nwords, q + Q0, q < nQ, r);
+  else gi = (q < nQ) ? locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r) : 0;
+  if (q >= nQ) return;
+  const size_t row = gi / g.W;
+  const int k = (int)(gi % g.W);
+  const int y = (int)(row % g.ny);
+  const int z = g.cz0 + (int)(row / g.ny);
+  u64 F[6];
+  faces_word(a.bits, g, y, z, k, F);
+  int lo = 0, hi = 64;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    int c = 0;
+#pragma unroll
+    for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
+    if ((u32)c <= r) lo = mid; else hi = mid;
+  }
+  int before = 0;
+  unsigned fm = 0;
+#pragma unroll
+  for (int f = 0; f < 6; f++) {
+    before += popc64(F[f] & lowmask(lo));
+    fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
+  }
+  emit_one_cell<TRI>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), q, V0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -711,9 +889,17 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 template <class T>
 __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
-                                                 int REFILL, Totals *__restrict__ tot) {
+                                                 int REFILL, int xcdRemap, Totals *__restrict__ tot) {
   const int lane = threadIdx.x & 63;
-  const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // blocks are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2): give
+  // every XCD one contiguous eighth of the vertex list so that chunks whose cells overlap (adjacent
+  // rows and slices) meet in the same L2.  Placement only affects speed, never results.
+  u64 lb = blockIdx.x;
+  if (xcdRemap) {
+    const u64 nb = gridDim.x, per = nb / 8, rem = nb % 8, x = lb % 8, j = lb / 8;
+    lb = x * per + (x < rem ? x : rem) + j;
+  }
+  const u64 wave = (lb * blockDim.x + threadIdx.x) >> 6;
   u64 next = wave * chunk;                        // wave-uniform cursor into this wave's chunk
   u64 end = next + chunk;
   if (end > nPoints) end = nPoints;
@@ -881,6 +1067,13 @@ hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, si
   return hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, out, (int)n, s);
 }
 
+hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s) {
+  if (!w.headV || !w.headQ) return hipSuccess;
+  hipLaunchKernelGGL(k_heads, dim3(grid_for(nwords, 256, 0)), dim3(256), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ,
+                     nwords, w.headV, w.headQ);
+  return hipGetLastError();
+}
+
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ, g, nwords,
                      w.totals);
@@ -895,14 +1088,21 @@ static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
   a.cells = w.cells;
   a.pointOffset = pointOffset;
   a.cmap = w.cmap;
+  a.headV = w.headV; a.headQ = w.headQ;
   return a;
 }
 
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s) {
   if (!nV) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const size_t nseg = (nwords + 63) >> 6;
-  hipLaunchKernelGGL(k_emit_points, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo, nseg, nwords, nV);
+  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 1;
+  if (w.headV && variant == 1) {
+    const size_t nseg = (nwords + 63) >> 6;
+    hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo, nseg, nwords, nV);
+  } else {
+    const unsigned blocks = (unsigned)((nwords + EMIT_WB - 1) / EMIT_WB);
+    hipLaunchKernelGGL(k_emit_points, dim3(blocks), dim3(256), 0, s, emit_args(w, 0), g, geo, nwords);
+  }
   return hipGetLastError();
 }
 
@@ -921,18 +1121,21 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
-  // contiguous chunk of vertices per wave: about 12 waves' worth per SIMD keeps the tail short
-  u64 chunk = (nPoints + 12287) / 12288;
-  chunk = (chunk + 63) / 64 * 64;
-  if (chunk < 256) chunk = 256;
-  const u64 nwaves = (nPoints + chunk - 1) / chunk;
+  // contiguous chunk of vertices per wave.  Small chunks keep the vertices in flight on the whole chip
+  // inside a narrow band of slices (measured at 1024^3: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms;
+  // 64, i.e. no refill at all, 2.76 ms)
+  u64 chunk = 256;
   int refill = 16;
   if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
+  int xcdRemap = 0;   // measured: remapping chunks per XCD is 1.6x SLOWER here (3.1 vs 1.9 ms), kept as a switch
+  if (const char *e = getenv("CUBERILLE_PROJ_XCD")) xcdRemap = atoi(e);
+  if (const char *e = getenv("CUBERILLE_PROJ_CHUNK")) { chunk = (u64)atoll(e); if (chunk < 64) chunk = 64; }
+  const u64 nwaves = (nPoints + chunk - 1) / chunk;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
-                       nPoints, nGhost, chunk, refill, w.totals);
+                       nPoints, nGhost, chunk, refill, xcdRemap, w.totals);
     return hipGetLastError();
   });
 }
