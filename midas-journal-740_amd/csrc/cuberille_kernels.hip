@@ -57,7 +57,7 @@ struct Vec16 {
 // Fast path: nx % 64 == 0, so the volume is a flat array of 64-voxel words.  Each lane
 // loads 16 B (VPL voxels), builds VPL bits; LPW = 64/VPL adjacent lanes OR their partial
 // words together.  One wave turns U KiB of voxels into U*VPL words per trip.
-template <class T, int U>
+template <class T, int U, bool NT>
 __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox, u64 *__restrict__ bits,
                                                        u64 nchunks, double isoD, u32 *__restrict__ sliceOcc,
                                                        u64 wordsPerSlice) {
@@ -72,8 +72,15 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
     Vec16<T> r[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (c + u < nchunks)
-        r[u].raw = *reinterpret_cast<const uint4 *>(vox + ((c + u) * 64 + lane) * VPL);
+      if (c + u < nchunks) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(vox + ((c + u) * 64 + lane) * VPL);
+        if (NT) {   // streamed once: keep it out of the way of the bit volume in L2 / Infinity Cache
+          r[u].raw.x = __builtin_nontemporal_load(&src->x); r[u].raw.y = __builtin_nontemporal_load(&src->y);
+          r[u].raw.z = __builtin_nontemporal_load(&src->z); r[u].raw.w = __builtin_nontemporal_load(&src->w);
+        } else {
+          r[u].raw = *src;
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -87,7 +94,6 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
       if (sub == 0) {
         const u64 widx = (c + u) * VPL + lane / LPW;
         bits[widx] = part;
-        if (part) sliceOcc[widx / wordsPerSlice] = 1u;   // benign race: every writer stores 1
       }
     }
   }
@@ -111,11 +117,30 @@ __global__ __launch_bounds__(256) void k_classify_rows(const T *__restrict__ vox
     bool in = false;
     if (x < nx) in = !(vox[row * (u64)nx + x] < iso);
     const u64 word = __ballot(in);
-    if (lane == 0) {
-      bits[t] = word;
-      if (word) sliceOcc[row / rowsPerSlice] = 1u;
-    }
+    if (lane == 0) bits[t] = word;
   }
+}
+
+// Per-slice occupancy (does the slice hold any inside voxel?) from the packed bits: one block per
+// slice, stops at the first non-zero word it sees.
+__global__ __launch_bounds__(256) void k_occupancy(const u64 *__restrict__ bits, size_t wordsPerSlice,
+                                                   u32 *__restrict__ sliceOcc) {
+  const u64 *p = bits + (size_t)blockIdx.x * wordsPerSlice;
+  __shared__ int found;
+  if (threadIdx.x == 0) found = 0;
+  __syncthreads();
+  for (size_t i0 = 0; i0 < wordsPerSlice; i0 += 1024) {
+    u64 v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const size_t i = i0 + j * 256 + threadIdx.x;
+      if (i < wordsPerSlice) v |= p[i];
+    }
+    if (v) found = 1;
+    __syncthreads();
+    if (found) break;
+  }
+  if (threadIdx.x == 0) sliceOcc[blockIdx.x] = found ? 1u : 0u;
 }
 
 // Empty-slice aliasing table (reference quirk Q1, txx:139-141 precede 156-161: the lookup
@@ -145,13 +170,15 @@ __global__ void k_alias(const u32 *__restrict__ sliceOcc, int *__restrict__ alia
 struct Rows3 { u64 m, c, p; };   // bit x = inside(x-1), inside(x), inside(x+1), border-clamped (I2)
 
 __device__ __forceinline__ Rows3 load_row(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k) {
+  // three unconditional loads (the neighbour indices are clamped, the selects are ALU): all 27 loads
+  // of a neighbourhood are independent and issue back to back, one memory latency in total
   const u64 *r = bits + ((size_t)z * g.ny + y) * g.W;
+  const int kp = k > 0 ? k - 1 : 0, kn = k < g.W - 1 ? k + 1 : k;
+  const u64 c = r[k], wp = r[kp], wn = r[kn];
   Rows3 o;
-  o.c = r[k];
-  const u64 prevb = (k > 0) ? (r[k - 1] >> 63) : (o.c & 1ull);
-  o.m = (o.c << 1) | prevb;
-  if (k < g.W - 1) o.p = (o.c >> 1) | (r[k + 1] << 63);
-  else o.p = (o.c >> 1) | (o.c & (1ull << g.lastpos));
+  o.c = c;
+  o.m = (c << 1) | (k > 0 ? (wp >> 63) : (c & 1ull));
+  o.p = (c >> 1) | (k < g.W - 1 ? (wn << 63) : (c & (1ull << g.lastpos)));
   return o;
 }
 
@@ -1024,14 +1051,27 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
     const bool aligned = ((uintptr_t)vox % 16) == 0;
     if (g.nx % 64 == 0 && aligned) {
       constexpr int VPL = 16 / sizeof(T);
-      constexpr int U = 4;
       const u64 nwordsAll = nrows * g.W;
       const u64 nchunks = nwordsAll / VPL;        // whole 1 KiB chunks; the < VPL words left go below
+      static const int variant = getenv("CUBERILLE_CLASSIFY_VARIANT") ? atoi(getenv("CUBERILLE_CLASSIFY_VARIANT")) : 3;
+      static const int gridCap = getenv("CUBERILLE_CLASSIFY_GRID") ? atoi(getenv("CUBERILLE_CLASSIFY_GRID")) : 2048;
       if (nchunks) {
         // 256 CUs x 8 blocks of 256 threads; grid-stride over the rest
-        const unsigned blocks = grid_for((nchunks + U - 1) / U * 64, 256, 2048);
-        hipLaunchKernelGGL((k_classify_flat<T, U>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nchunks, iso, w.sliceOcc,
-                           (u64)g.ny * g.W);
+        auto go = [&](auto uTag, auto ntTag) {
+          constexpr int U = decltype(uTag)::value;
+          constexpr bool NT = decltype(ntTag)::value;
+          const unsigned blocks = grid_for((nchunks + U - 1) / U * 64, 256, gridCap);
+          hipLaunchKernelGGL((k_classify_flat<T, U, NT>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nchunks, iso, w.sliceOcc,
+                             (u64)g.ny * g.W);
+        };
+        switch (variant) {
+          case 1: go(std::integral_constant<int, 4>(), std::true_type()); break;
+          case 2: go(std::integral_constant<int, 8>(), std::false_type()); break;
+          case 3: go(std::integral_constant<int, 8>(), std::true_type()); break;
+          case 4: go(std::integral_constant<int, 2>(), std::false_type()); break;
+          case 0: go(std::integral_constant<int, 4>(), std::false_type()); break;
+          default: go(std::integral_constant<int, 8>(), std::true_type()); break;   // measured best: 8 KiB per wave trip, nontemporal
+        }
       }
       if (nchunks * VPL < nwordsAll)
         hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, nchunks * VPL, nrows,
@@ -1047,6 +1087,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
 }
 
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s) {
+  hipLaunchKernelGGL(k_occupancy, dim3(g.nzb), dim3(256), 0, s, w.bits, (size_t)g.ny * g.W, w.sliceOcc);
   hipLaunchKernelGGL(k_alias, dim3((g.nzb + 255) / 256), dim3(256), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
   return hipGetLastError();
 }
