@@ -125,10 +125,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
             args.gpus, world, args.gpus))
+    # CUBERILLE_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a functional rehearsal of
+    # the N>1 path on a one-GPU box (never a measurement)
+    rehearsal = os.environ.get("CUBERILLE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     pkg = graft.load_package()
     pkg._abi.build()
     from midas_journal_740_amd.distributed import ShardedExtractor
@@ -152,6 +160,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -170,10 +179,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        cdev = "cpu" if rehearsal else device
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([int(res.n_points), int(res.n_cells)], dtype=torch.int64, device=device)
+        tot = torch.tensor([int(res.n_points), int(res.n_cells)], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         n_points, n_cells = int(tot[0]), int(tot[1])
     else:
@@ -196,7 +206,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if dtype == np.float32 else "u8",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": "%s %dx%dx%d %s iso=%g, triangles+projection (thr %g, step 0.25, relax 0.95, max 50)"
                                    % (args.workload, n, n, gnz, np.dtype(dtype).name, iso, thr),
                        "per_gpu": "%dx%dx%d slab + %d-slice halo" % (n, n, sh.z1 - sh.z0, 8 if world > 1 else 0),

@@ -37,6 +37,15 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
     Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together."""
     import torch.distributed as dist
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
+        host = buf.cpu()
+        exchange_halos(host, lo, hi, z0, z1, rank, world, group)
+        if z0 > lo:
+            buf[:z0 - lo].copy_(host[:z0 - lo])
+        if hi > z1:
+            buf[z1 - lo:].copy_(host[z1 - lo:])
+        return buf
     ops, keep = [], []
     nlo, nhi = z0 - lo, hi - z1                     # halo depth below / above
     if rank > 0 and nlo > 0:
@@ -67,6 +76,8 @@ def gather_counts(n_points, n_cells, device, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
     mine = torch.tensor([int(n_points), int(n_cells)], dtype=torch.int64, device=device)
     out = torch.empty(world * 2, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine, group=group)
