@@ -926,11 +926,17 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
     const u64 nb = gridDim.x, per = nb / 8, rem = nb % 8, x = lb % 8, j = lb / 8;
     lb = x * per + (x < rem ? x : rem) + j;
   }
+  // Work assignment: the vertex list is cut into batches of `chunk` (a power of two) vertices; wave w
+  // takes batches w, w+NW, w+2NW, ... (NW = waves in the grid).  With the grid resident, all waves
+  // advance through the list together, so the vertices in flight on the chip stay inside a narrow
+  // band of slices; `next` counts positions in the wave's own sequence.
   const u64 wave = (lb * blockDim.x + threadIdx.x) >> 6;
-  u64 next = wave * chunk;                        // wave-uniform cursor into this wave's chunk
-  u64 end = next + chunk;
-  if (end > nPoints) end = nPoints;
-  if (next >= end) return;
+  const u64 NW = ((u64)gridDim.x * blockDim.x) >> 6;
+  const int lgChunk = 63 - __clzll((long long)chunk);
+  const u64 nBatches = (nPoints + chunk - 1) >> lgChunk;
+  if (wave >= nBatches) return;
+  u64 next = 0;                                   // wave-uniform cursor
+  const u64 end = ((nBatches - wave + NW - 1) / NW) << lgChunk;
   Sampler<T> s{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
   const int n[3] = {g.nx, g.ny, (int)g.gnz};
   const double iso = (double)(T)prm.iso;
@@ -949,8 +955,10 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
       const u64 remaining = end - next;
       if (!active) {
         const u64 rank = (u64)__popcll(idle & lowmask(lane));
-        if (rank < remaining) {
-          idx = next + rank;
+        const u64 pos = next + rank;
+        const u64 cand = ((wave + (pos >> lgChunk) * NW) << lgChunk) + (pos & (chunk - 1));
+        if (rank < remaining && cand < nPoints) {
+          idx = cand;
           vertex[0] = points[3 * idx]; vertex[1] = points[3 * idx + 1]; vertex[2] = points[3 * idx + 2];
           step = prm.step;
           numberOfSteps = 0;
@@ -1162,16 +1170,19 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
-  // contiguous chunk of vertices per wave.  Small chunks keep the vertices in flight on the whole chip
-  // inside a narrow band of slices (measured at 1024^3: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms;
-  // 64, i.e. no refill at all, 2.76 ms)
-  u64 chunk = 256;
+  // batches of 128 vertices dealt round-robin to 8192 waves (measured at 1024^3: 1.46 ms; one contiguous
+  // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)
+  u64 chunk = 128;
+  u64 gridWaves = 8192;
+  if (const char *e = getenv("CUBERILLE_PROJ_WAVES")) gridWaves = (u64)atoll(e);
   int refill = 16;
   if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
   int xcdRemap = 0;   // measured: remapping chunks per XCD is 1.6x SLOWER here (3.1 vs 1.9 ms), kept as a switch
   if (const char *e = getenv("CUBERILLE_PROJ_XCD")) xcdRemap = atoi(e);
   if (const char *e = getenv("CUBERILLE_PROJ_CHUNK")) { chunk = (u64)atoll(e); if (chunk < 64) chunk = 64; }
-  const u64 nwaves = (nPoints + chunk - 1) / chunk;
+  while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
+  u64 nwaves = (nPoints + chunk - 1) / chunk;
+  if (gridWaves && nwaves > gridWaves) nwaves = gridWaves;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
