@@ -790,16 +790,23 @@ struct Cell8 {
   double d[3];
 };
 
-__device__ __forceinline__ void make_cell(const Geo &geo, const int n[3], const double p[3], Cell8 &c) {
+__device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const int n[3], const double p[3], Cell8 &c) {
   double cv[3], ci[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) cv[k] = p[k] - geo.origin[k];                // I4
+  if (unitP2I) {
+    // identity PhysicalPointToIndex matrix: 0 + 1*a + 0*b + 0*c is a + 0 for every a, b, c a vertex
+    // can hold (finite or NaN), including the -0 -> +0 of the leading 0 +
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    double sum = 0.0;
+    for (int r = 0; r < 3; r++) ci[r] = cv[r] + 0.0;
+  } else {
 #pragma unroll
-    for (int k = 0; k < 3; k++) sum += geo.p2i[r * 3 + k] * cv[k];
-    ci[r] = sum;
+    for (int r = 0; r < 3; r++) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sum += geo.p2i[r * 3 + k] * cv[k];
+      ci[r] = sum;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -914,9 +921,9 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // and shrink): the per-iteration work is then the trilinear weights, 32 multiply-adds, one sqrt
 // and three divides, all in f64 in the reference's operation order.
 template <class T>
-__global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
-                                                 int REFILL, int xcdRemap, Totals *__restrict__ tot) {
+                                                 int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot) {
   const int lane = threadIdx.x & 63;
   // blocks are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2): give
   // every XCD one contiguous eighth of the vertex list so that chunks whose cells overlap (adjacent
@@ -949,6 +956,10 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
   int kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};           // cell held in registers
   float G[8][3];
   double Vd[8];
+  bool cellFinite = false;
+  bool unitP2I = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) unitP2I = unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
   for (;;) {
     const u64 idle = __ballot(!active);
     if (idle && next < end && (__popcll(idle) >= REFILL || idle == ~0ull)) {
@@ -975,25 +986,55 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ vox, Grid
       bool done = false;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
-      make_cell(geo, n, p, c);
+      make_cell(geo, unitP2I, n, p, c);
       if (c.lo[0] != kl[0] || c.lo[1] != kl[1] || c.lo[2] != kl[2] || c.hi[0] != kh[0] || c.hi[1] != kh[1] ||
           c.hi[2] != kh[2]) {
         gather_cell(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
         for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
+        cellFinite = true;
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++)
+          cellFinite = cellFinite && finite_f((float)Vd[counter]) && finite_f(G[counter][0]) && finite_f(G[counter][1]) &&
+                       finite_f(G[counter][2]);
       }
-      // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights
-      double acc[3] = {0.0, 0.0, 0.0}, value = 0.0, total = 0.0;
+      // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
+      // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite
+      // pixels a zero weight adds nothing, so only the early stop can change bits: when no partial
+      // sum of the weights hits 1.0 before the last term (the usual case) the eight terms are summed
+      // straight; otherwise, or with non-finite pixels in the cell, the loop is replayed literally.
+      double o[8];
 #pragma unroll
       for (unsigned counter = 0; counter < 8; counter++) {
         double overlap = 1.0;
 #pragma unroll
         for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
-        if (overlap != 0.0 && total != 1.0) {     // "if (overlap)" + "break once total == 1"
+        o[counter] = overlap;
+      }
+      bool literal = !cellFinite || forceLiteral;
+      {
+        double t = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += overlap * (double)G[counter][k];
-          value += overlap * Vd[counter];
-          total += overlap;
+        for (int counter = 0; counter < 7; counter++) { t += o[counter]; literal |= (t == 1.0); }
+      }
+      double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
+      if (!literal) {
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+          value += o[counter] * Vd[counter];
+        }
+      } else {
+        double total = 0.0;
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+          if (o[counter] != 0.0 && total != 1.0) {   // "if (overlap)" + "break once total == 1"
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+            value += o[counter] * Vd[counter];
+            total += o[counter];
+          }
         }
       }
       done = fabs(value - iso) < prm.thr;                                     // txx:456
@@ -1177,6 +1218,7 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (const char *e = getenv("CUBERILLE_PROJ_WAVES")) gridWaves = (u64)atoll(e);
   int refill = 16;
   if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
+  static const int forceLiteral = getenv("CUBERILLE_PROJ_LITERAL") ? atoi(getenv("CUBERILLE_PROJ_LITERAL")) : 0;
   int xcdRemap = 0;   // measured: remapping chunks per XCD is 1.6x SLOWER here (3.1 vs 1.9 ms), kept as a switch
   if (const char *e = getenv("CUBERILLE_PROJ_XCD")) xcdRemap = atoi(e);
   if (const char *e = getenv("CUBERILLE_PROJ_CHUNK")) { chunk = (u64)atoll(e); if (chunk < 64) chunk = 64; }
@@ -1187,7 +1229,7 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
-                       nPoints, nGhost, chunk, refill, xcdRemap, w.totals);
+                       nPoints, nGhost, chunk, refill, xcdRemap, forceLiteral, w.totals);
     return hipGetLastError();
   });
 }
