@@ -54,6 +54,37 @@ struct Vec16 {
   union { uint4 raw; T v[N]; };
 };
 
+// inside-bits of the 16/sizeof(T) pixels of one 16-byte load: bit j = !(pixel j < iso)
+template <class T>
+__device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
+  if constexpr (sizeof(T) == 1) {
+    // 1-byte pixels, SWAR on the packed dwords (byte-wise extraction would blow the 16 bytes of every
+    // load up into 16 registers: 146 VGPRs and 3 waves per SIMD instead of 8).  Per byte, unsigned
+    // x >= t: with xl, tl the low 7 bits, bit 7 of ((xl | 0x80) - tl) says xl >= tl (no borrow crosses
+    // bytes), and x >= t is (x7 | that) when t < 128, (x7 & that) when t >= 128.  Signed pixels are
+    // biased by 0x80 first.  The four bit-7s are gathered into a nibble by one multiply.
+    const u32 bias = std::is_signed<T>::value ? 0x80808080u : 0u;
+    const u32 t = ((u32)(unsigned char)iso) ^ (bias & 0x80u);
+    const u32 tl = (t & 0x7fu) * 0x01010101u;
+    const bool thigh = (t & 0x80u) != 0;
+    const u32 w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+    u32 m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u32 x = w[j] ^ bias;
+      const u32 d = ((x & 0x7f7f7f7fu) | 0x80808080u) - tl;
+      const u32 ge = (thigh ? (x & d) : (x | d)) & 0x80808080u;
+      m |= ((((ge >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * j);
+    }
+    return m;
+  } else {
+    u32 m = 0;
+#pragma unroll
+    for (int j = 0; j < Vec16<T>::N; j++) m |= (!(r.v[j] < iso) ? 1u : 0u) << j;
+    return m;
+  }
+}
+
 // Fast path: nx % 64 == 0, so the volume is a flat array of 64-voxel words.  Each lane
 // loads 16 B (VPL voxels), builds VPL bits; LPW = 64/VPL adjacent lanes OR their partial
 // words together.  One wave turns U KiB of voxels into U*VPL words per trip.
@@ -85,9 +116,7 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (c + u >= nchunks) break;            // wave-uniform
-      u32 m = 0;
-#pragma unroll
-      for (int j = 0; j < VPL; j++) m |= (!(r[u].v[j] < iso) ? 1u : 0u) << j;
+      const u32 m = inside_bits<T>(r[u], iso);
       u64 part = (u64)m << (sub * VPL);
 #pragma unroll
       for (int s = 1; s < LPW; s <<= 1) part |= __shfl_xor(part, s, 64);
@@ -1211,10 +1240,11 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
-  // batches of 128 vertices dealt round-robin to 8192 waves (measured at 1024^3: 1.46 ms; one contiguous
+  // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms
+  // for one contiguous chunk of 256 per wave; u8 noise prefers contiguous, 2.23 vs 2.35 ms; earlier runs:
   // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)
   u64 chunk = 128;
-  u64 gridWaves = 8192;
+  u64 gridWaves = 16384;
   if (const char *e = getenv("CUBERILLE_PROJ_WAVES")) gridWaves = (u64)atoll(e);
   int refill = 16;
   if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
