@@ -91,7 +91,7 @@ __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
 template <class T, int U, bool NT>
 __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox, u64 *__restrict__ bits,
                                                        u64 nchunks, double isoD, u32 *__restrict__ sliceOcc,
-                                                       u64 wordsPerSlice) {
+                                                       int lgWordsPerSlice) {
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
   const T iso = (T)isoD;
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
       if (sub == 0) {
         const u64 widx = (c + u) * VPL + lane / LPW;
         bits[widx] = part;
+        // slice occupancy on the fly when a slice is 2^n words (else k_occupancy derives it afterwards)
+        if (lgWordsPerSlice >= 0 && part) sliceOcc[widx >> lgWordsPerSlice] = 1u;   // benign race: all store 1
       }
     }
   }
@@ -310,39 +312,74 @@ __device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, cons
   }
 }
 
+__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]);
+
 // ---------------------------------------------------------------------------------------------
-// K2: count.  One lane per word, one wave per 64-word segment of the flat raster order.
+// K2: count.  A block owns COUNT_WB consecutive words of the flat raster order (32 scan segments).
+//   phase 1  every word: the six face masks (7 bit-rows) -> quad count; words with a face are
+//            queued in LDS (a voxel only creates corners on faces it emits, so words without a
+//            face create nothing)
+//   phase 2  one lane per QUEUED word: the 8 created-corner masks (27 bit-rows, ~600 ALU ops) ->
+//            vertex count.  The surface touches a fraction of the words, so the expensive part
+//            runs on densely packed lanes instead of on every word.
+//   phase 3  one wave per segment: exclusive scan of the packed counts -> prefix, segment totals.
 // ---------------------------------------------------------------------------------------------
+constexpr int COUNT_WB = 2048;
+
 __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const int *__restrict__ alias, Grid g,
                                                size_t nwords, u32 *__restrict__ prefix, u64 *__restrict__ segV,
                                                u64 *__restrict__ segQ) {
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  u32 packed = 0;
-  if (gi < nwords) {
+  __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
+  __shared__ unsigned short queue[COUNT_WB];
+  __shared__ int nQueued;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
+  if (tid == 0) nQueued = 0;
+  __syncthreads();
+  for (int i = tid; i < COUNT_WB; i += 256) {
+    const size_t gi = w0 + i;
+    u32 packed = 0;
+    if (gi < nwords) {
+      const size_t row = gi / g.W;
+      u64 F[6];
+      faces_word(bits, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), F);
+      int nQ = 0;
+#pragma unroll
+      for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
+      packed = (u32)nQ << 16;
+      if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
+    }
+    cnt[i] = packed;
+  }
+  __syncthreads();
+  const int nq = nQueued;
+  for (int j = tid; j < nq; j += 256) {
+    const int i = queue[j];
+    const size_t gi = w0 + i;
     const size_t row = gi / g.W;
-    const int k = (int)(gi % g.W);
-    const int y = (int)(row % g.ny);
-    const int z = g.cz0 + (int)(row / g.ny);
     WordInfo w;
-    classify_word(bits, alias, g, y, z, k, w);
-    int nV = 0, nQ = 0;
+    classify_word(bits, alias, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), w);
+    int nV = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) nV += popc64(w.C[i]);
-#pragma unroll
-    for (int f = 0; f < 6; f++) nQ += popc64(w.F[f]);
-    packed = (u32)nV | ((u32)nQ << 16);   // <= 512 and <= 384 per word: the packed scan cannot carry
+    for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
+    cnt[i] |= (u32)nV;
   }
-  u32 incl = packed;
+  __syncthreads();
+  for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
+    const size_t gi = w0 + sg * 64 + lane;
+    if ((gi & ~(size_t)63) >= nwords) break;    // wave-uniform
+    const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
+    u32 incl = packed;
 #pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    const u32 t = __shfl_up(incl, s, 64);
-    if (lane >= s) incl += t;
-  }
-  if (gi < nwords) prefix[gi] = incl - packed;
-  if (lane == 63 && (gi & ~(size_t)63) < nwords) {
-    segV[gi >> 6] = incl & 0xffffu;
-    segQ[gi >> 6] = incl >> 16;
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const u32 t = __shfl_up(incl, sft, 64);
+      if (lane >= sft) incl += t;
+    }
+    if (gi < nwords) prefix[gi] = incl - packed;
+    if (lane == 63) {
+      segV[gi >> 6] = incl & 0xffffu;
+      segQ[gi >> 6] = incl >> 16;
+    }
   }
 }
 
@@ -1121,6 +1158,16 @@ static inline unsigned grid_for(u64 threads, unsigned block, unsigned cap) {
   return (unsigned)b;
 }
 
+// log2(words per slice) when the flat classify kernel can set the slice occupancy itself, else -1
+static int occupancy_shift(const Grid &g) {
+  const u64 wps = (u64)g.ny * g.W;
+  if (g.nx % 64 != 0 || (wps & (wps - 1)) != 0) return -1;
+  if (((u64)g.nzb * wps) % 16 != 0) return -1;    // a ragged tail goes through k_classify_rows
+  int lg = 0;
+  while ((1ull << lg) < wps) lg++;
+  return lg;
+}
+
 hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, hipStream_t s) {
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
@@ -1140,7 +1187,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
           constexpr bool NT = decltype(ntTag)::value;
           const unsigned blocks = grid_for((nchunks + U - 1) / U * 64, 256, gridCap);
           hipLaunchKernelGGL((k_classify_flat<T, U, NT>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nchunks, iso, w.sliceOcc,
-                             (u64)g.ny * g.W);
+                             occupancy_shift(g));
         };
         switch (variant) {
           case 1: go(std::integral_constant<int, 4>(), std::true_type()); break;
@@ -1165,13 +1212,14 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, do
 }
 
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s) {
-  hipLaunchKernelGGL(k_occupancy, dim3(g.nzb), dim3(256), 0, s, w.bits, (size_t)g.ny * g.W, w.sliceOcc);
+  if (occupancy_shift(g) < 0 || ((uintptr_t)w.vox % 16) != 0)
+    hipLaunchKernelGGL(k_occupancy, dim3(g.nzb), dim3(256), 0, s, w.bits, (size_t)g.ny * g.W, w.sliceOcc);
   hipLaunchKernelGGL(k_alias, dim3((g.nzb + 255) / 256), dim3(256), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
   return hipGetLastError();
 }
 
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
-  const unsigned blocks = grid_for(nwords, 256, 0);
+  const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.alias, g, nwords, w.prefix, w.segV, w.segQ);
   return hipGetLastError();
 }
