@@ -846,9 +846,9 @@ struct Sampler {
 };
 
 __device__ __forceinline__ int to_index_clamped(double b, int end) {
-  if (!(b >= 0.0)) return 0;            // also NaN (quirk Q4): never read out of bounds
-  if (b >= (double)end) return end;
-  return (int)b;
+  // branch-free: fmax(NaN, 0) is 0, so a NaN coordinate (quirk Q4) lands on index 0 and never reads
+  // out of bounds; b is integral (a floor), so the clamp in double and the conversion are exact
+  return (int)fmin(fmax(b, 0.0), (double)end);
 }
 
 struct Cell8 {
@@ -1058,11 +1058,14 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         gather_cell(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
         for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
-        cellFinite = true;
+        u32 emax = 0;                             // largest exponent field among the 32 cached floats
 #pragma unroll
-        for (int counter = 0; counter < 8; counter++)
-          cellFinite = cellFinite && finite_f((float)Vd[counter]) && finite_f(G[counter][0]) && finite_f(G[counter][1]) &&
-                       finite_f(G[counter][2]);
+        for (int counter = 0; counter < 8; counter++) {
+          emax = max(emax, __float_as_uint((float)Vd[counter]) & 0x7f800000u);
+#pragma unroll
+          for (int k = 0; k < 3; k++) emax = max(emax, __float_as_uint(G[counter][k]) & 0x7f800000u);
+        }
+        cellFinite = emax != 0x7f800000u;
       }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
       // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite
