@@ -10,6 +10,7 @@
 #include "cuberille_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -308,14 +309,14 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   // dense corner -> vertex map (4 B per lattice corner of the buffer); when it cannot be had
   // (more than 2^32 vertices, or no memory) the cell kernel recomputes ids instead
   w.cmap = nullptr;
-  if (nV < 0xffffffffULL) {
+  if (nV < 0xffffffffULL && !getenv("CUBERILLE_NO_CMAP")) {   // (the variable exists for the tests of the fallback)
     const size_t mapBytes = (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 1) * sizeof(u32);
     if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
     else (void)hipGetLastError();
   }
   // head tables for the per-wave inverse mapping (4 B per 64 outputs)
   w.headV = w.headQ = nullptr;
-  if (c->nwords < 0xffffffffULL && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess &&
+  if (c->nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_HEADS") && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess &&
       c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) {
     w.headV = (u32 *)c->headV.p;
     w.headQ = (u32 *)c->headQ.p;

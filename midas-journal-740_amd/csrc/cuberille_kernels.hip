@@ -734,7 +734,7 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
 }
 
 // one quad (or its two triangles): corner ids from the dense map, Q1 redirect, fused diagonal split
-template <bool TRI>
+template <bool TRI, bool MAP>
 __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 q, u64 V0) {
   const int zp = a.alias[z];
   u64 lid[4];                                    // vertex index in the counted range
@@ -754,7 +754,10 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
       }
       if (hit) cz = zp + 1;
     }
-    lid[c] = a.cmap ? (u64)a.cmap[corner_map_index(g, cx, cy, cz)] : corner_id_generic(a, g, cx, cy, cz);
+    // MAP: ids from the dense corner map; otherwise recomputed (kept out of the MAP instantiation: its
+    // 27-row classification would cost the common kernel a quarter of its wave slots)
+    if (MAP) lid[c] = (u64)a.cmap[corner_map_index(g, cx, cy, cz)];
+    else lid[c] = corner_id_generic(a, g, cx, cy, cz);
   }
   u64 id[4];
 #pragma unroll
@@ -787,7 +790,7 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
 
 // K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
 // (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
-template <bool TRI>
+template <bool TRI, bool MAP>
 __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
     before += popc64(F[f] & lowmask(lo));
     fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
   }
-  emit_one_cell<TRI>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), q, V0);
+  emit_one_cell<TRI, MAP>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), q, V0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1281,8 +1284,11 @@ hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   const size_t nseg = (nwords + 63) >> 6;
   const EmitArgs a = emit_args(w, pointOffset);
-  if (triangles) hipLaunchKernelGGL(k_emit_cells<true>, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
-  else hipLaunchKernelGGL(k_emit_cells<false>, dim3(grid_for(nQ, 256, 0)), dim3(256), 0, s, a, g, nseg, nwords, nQ);
+  const dim3 grid(grid_for(nQ, 256, 0)), block(256);
+  if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nseg, nwords, nQ);
+  else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nseg, nwords, nQ);
+  else if (a.cmap) hipLaunchKernelGGL((k_emit_cells<false, true>), grid, block, 0, s, a, g, nseg, nwords, nQ);
+  else hipLaunchKernelGGL((k_emit_cells<false, false>), grid, block, 0, s, a, g, nseg, nwords, nQ);
   return hipGetLastError();
 }
 

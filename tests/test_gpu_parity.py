@@ -319,3 +319,18 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world):
     m = M()
     m.points, m.cells = pts, cells
     assert_same_mesh(m, ref)
+
+
+@pytest.mark.parametrize("env", ["CUBERILLE_NO_CMAP", "CUBERILLE_NO_HEADS"])
+def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, monkeypatch, env):
+    """When the dense corner map (4 B per lattice corner) or the head tables cannot be allocated the
+    kernels recompute ids / search the prefix arrays instead; same mesh either way."""
+    monkeypatch.setenv(env, "1")
+    rng = np.random.default_rng(11)
+    vox = rng.integers(0, 255, size=(9, 10, 130), dtype=np.uint8)
+    vox[4] = 0                                    # an empty slice: exercises the aliasing redirect too
+    for vol, iso in [(volumes("nucleon.mha"), 128), (volumes("silicium.mha"), 85), (pkg.Volume(vox), 128)]:
+        for tri in (0, 1):
+            kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+            mesh = run_gpu(pkg, extractor, vol, iso, **kw)
+            assert_same_mesh(mesh, oracle.run(vol.voxels, iso, **kw))
