@@ -334,3 +334,81 @@ def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, 
             kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
             mesh = run_gpu(pkg, extractor, vol, iso, **kw)
             assert_same_mesh(mesh, oracle.run(vol.voxels, iso, **kw))
+
+
+def _closed_form_counts_torch(ins):
+    """(#points, #quads) of the closed form on a bool tensor [z,y,x] on the GPU."""
+    import torch
+    quads = 0
+    for ax in range(3):
+        a = ins.movedim(ax, 0)
+        quads += int((a[1:] != a[:-1]).sum())
+    p = torch.nn.functional.pad(ins[None, None].to(torch.uint8), (1, 1, 1, 1, 1, 1), mode="replicate")[0, 0].bool()
+    nz, ny, nx = ins.shape
+    all_in = torch.ones((nz + 1, ny + 1, nx + 1), dtype=torch.bool, device=ins.device)
+    any_in = torch.zeros_like(all_in)
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                s = p[dz:dz + nz + 1, dy:dy + ny + 1, dx:dx + nx + 1]
+                all_in &= s
+                any_in |= s
+    return int((any_in & ~all_in).sum()), quads
+
+
+def test_1024_marschner_lobb_properties(pkg, extractor):
+    """BASELINE.json configs[3] at full size (the bench workload), where the oracle would take minutes:
+    size-independent properties.  (1) counts equal the closed form; (2) without projection every vertex is
+    a distinct lattice corner - 1/2; (3) the quad mesh is closed: every edge is used by 2 or 4 quads, and
+    every vertex by at least 3; (4) triangles = 2 x quads and use the same vertex set; (5) extracting the
+    volume as four Z-slabs (the multi-GPU decomposition) gives bit-identical buffers."""
+    import torch
+    n = 1024
+    vol = torch.cat([pkg.volumes.marschner_lobb(n, a, min(a + 64, n), xp=torch, device="cuda") for a in range(0, n, 64)])
+    desc = pkg.make_desc(np.float32, (n, n, n))
+    want_pts, want_quads = _closed_form_counts_torch(vol >= 0.5)
+    # (1)-(3): quads, no projection
+    prm = pkg.make_params(0.5, triangles=False, project=False)
+    extractor.extract_device(vol.data_ptr(), desc, prm)
+    mesh = extractor.download()
+    assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (want_pts, want_quads)
+    p2 = torch.from_numpy(mesh.points).cuda() * 2.0
+    assert bool((p2 == p2.round()).all()) and bool((p2.long() % 2 == 1).all())          # x.5 coordinates
+    key = (p2[:, 2].long() * (2 * n + 2) + p2[:, 1].long()) * (2 * n + 2) + p2[:, 0].long()
+    assert int(torch.unique(key).numel()) == want_pts                                  # no duplicate vertex
+    q = torch.from_numpy(mesh.cells.astype(np.int64)).cuda()
+    assert int(q.min()) == 0 and int(q.max()) == want_pts - 1
+    e = torch.cat([torch.stack([q[:, i], q[:, (i + 1) % 4]], 1) for i in range(4)])
+    e = torch.sort(e, dim=1).values
+    _, mult = torch.unique(e[:, 0] * want_pts + e[:, 1], return_counts=True)
+    assert set(torch.unique(mult).tolist()) <= {2, 4}
+    assert int(torch.bincount(q.reshape(-1), minlength=want_pts).min()) >= 3
+    del e, mult, key, p2
+    # (4) triangles + projection (the bench configuration)
+    prm = pkg.make_params(0.5, triangles=True, project=True, threshold=0.002, step=0.25, relax=0.95, max_steps=50)
+    res = extractor.extract_device(vol.data_ptr(), desc, prm)
+    tri = extractor.download()
+    assert (tri.GetNumberOfPoints(), tri.GetNumberOfCells()) == (want_pts, 2 * want_quads)
+    t = torch.from_numpy(tri.cells.astype(np.int64)).cuda().reshape(-1, 6)
+    for i in range(4):                                             # two triangles of a quad use exactly its 4 ids
+        assert bool((t == q[:, i:i + 1]).any(1).all())
+    for j in range(6):
+        assert bool((q == t[:, j:j + 1]).any(1).all())
+    assert np.isfinite(tri.points).all() and res.proj_iterations >= want_pts
+    moved = np.abs(tri.points - mesh.points).max()
+    assert 0.0 < moved < 4.81                                      # step * sum(relax^k), k <= 51
+    # (5) four slabs with an 8-slice halo == one shot, bit for bit
+    pts, cells, poff = [], [], 0
+    cuts = [0, 200, 512, 513, 1024]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo, hi = max(a - 8, 0), min(b + 8, n)
+        sdesc = pkg.make_desc(np.float32, (n, n, hi - lo))
+        slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
+        n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), sdesc, prm, slab)
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert np.array_equal(np.concatenate(cells), tri.cells)
+    assert np.array_equal(np.concatenate(pts).view(np.uint32), tri.points.view(np.uint32))
