@@ -4,22 +4,26 @@
 //   /root/reference/Source/itkCuberilleImageToMeshFilter.txx:136-206 (sweep),
 //   256-332 (AddVertex/AddQuadFace), 439-474 (projection), 478-498 (gradient).
 //
-// Design: the order-dependent raster sweep with its two
-// std::map lookups is replaced by a closed form over a packed inside-bit volume:
-//   classify : one coalesced pass over the voxels, 16 B per lane, thresholds against
-//              the iso value and packs 64 voxels per uint64 word (wave ballot /
-//              cross-lane OR)                                        -> bits
-//   count    : one lane per 64-voxel word, SWAR boolean algebra over the 27
-//              neighbour bit-rows gives the 6 face masks and the 8 "this voxel
-//              creates corner i" masks; popcounts + a wavefront scan give the
-//              in-segment exclusive prefix                           -> prefix, seg totals
-//   scan     : hipCUB exclusive sum over the per-segment totals      -> segBase
-//   emit     : points and quads written at their final, reference-order indices
-//   project  : one lane per vertex, the damped gradient walk with the gradient
-//              image evaluated on the fly (never materialised)
-//   triangulate : shorter-diagonal split on the projected coordinates.
+// Design (DESIGN.md sections 4-5): the order-dependent raster sweep with its two std::map lookups
+// is replaced by a closed form over a packed inside-bit volume:
+//   classify : one coalesced, nontemporal pass over the voxels, 16 B per lane, thresholds against the
+//              iso value and packs 64 voxels per uint64 word (cross-lane OR)      -> bits
+//   count    : per block of 2048 words: face masks for every word, then one lane per word that has a
+//              face: SWAR boolean algebra over the 27 neighbour bit-rows gives the 8 "this voxel
+//              creates corner i" masks; popcounts + a wavefront scan per 64-word segment
+//                                                                                -> prefix, seg totals
+//   scan     : hipCUB exclusive sum over the per-segment totals                  -> segBase
+//   emit     : one lane per OUTPUT (vertex / quad), located by a per-wave search of the prefix
+//              arrays; points and cells land at their final, reference-order indices; corner ids
+//              through a dense lattice-corner map
+//   project  : refilling waves, the damped gradient walk with the gradient image evaluated on the
+//              fly (never materialised); runs between the point and the cell pass so that the
+//              shorter-diagonal triangle split is fused into the cell pass.
 // Bit-exactness of the floating-point part against the CPU oracle relies on
 // -ffp-contract=off (no FMA fusion) and IEEE f64 div/sqrt; see csrc/Makefile.
+// Tuning switches read from the environment (defaults are the measured best): CUBERILLE_PROJ_CHUNK,
+// CUBERILLE_PROJ_WAVES, CUBERILLE_PROJ_REFILL, CUBERILLE_PROJ_XCD, CUBERILLE_PROJ_LITERAL,
+// CUBERILLE_CLASSIFY_VARIANT, CUBERILLE_CLASSIFY_GRID, CUBERILLE_POINTS_VARIANT.
 
 #include "cuberille_internal.h"
 #include "../../include/cuberille_hip.h"
