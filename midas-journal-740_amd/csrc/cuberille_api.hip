@@ -43,7 +43,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ;
+  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ, vqueue;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   // state of the last count
@@ -168,7 +168,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->occ, &c->alias, &c->prefix, &c->segV, &c->segQ, &c->segBaseV,
-                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ};
+                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -254,6 +254,10 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   const size_t tempBytes = scan_temp_bytes(nseg);
   HIP_TRY(c, c->scanTemp.reserve(tempBytes));
   Workspace w{};
+  w.vqueue = nullptr;
+  if (nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_VQUEUE") && c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess)
+    w.vqueue = (u32 *)c->vqueue.p;
+  else (void)hipGetLastError();
   w.vox = dev_voxels;
   w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)c->occ.p; w.alias = (int *)c->alias.p;
   w.prefix = (u32 *)c->prefix.p;
@@ -316,15 +320,15 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   }
   // head tables for the per-wave inverse mapping (4 B per 64 outputs)
   w.headV = w.headQ = nullptr;
-  if (c->nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_HEADS") && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess &&
-      c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) {
-    w.headV = (u32 *)c->headV.p;
-    w.headQ = (u32 *)c->headQ.p;
+  if (c->nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_HEADS")) {
+    if (c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) w.headQ = (u32 *)c->headQ.p;
+    if (!w.vqueue && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess) w.headV = (u32 *)c->headV.p;
+    (void)hipGetLastError();
   }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
   HIP_TRY(c, launch_heads(w, c->nwords, s));
-  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, s));
+  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, c->tot.nVertexWords, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));
   HIP_TRY(c, hipEventRecord(c->ev[6], s));

@@ -42,7 +42,7 @@ struct Totals {        // device-resident, mirrored to pinned host memory
   u64 V0, Q0;          // of which before the first owned slice
   u64 iters;           // projection iterations (atomic)
   u32 err;             // device-side error flags
-  u32 pad;
+  u32 nVertexWords;   // entries in the vertex-word queue (words that create at least one vertex)
 };
 
 enum { ERRF_ALIAS_UNKNOWN = 1 };
@@ -60,6 +60,7 @@ struct Workspace {     // device pointers valid for one count/emit pair
   u64 *cells;
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
   u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
+  u32 *vqueue;         // counted-range indices of the words that create vertices, in no particular order (or null)
 };
 
 struct Params {
@@ -75,7 +76,7 @@ hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s);
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
-hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s);
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, hipStream_t s);

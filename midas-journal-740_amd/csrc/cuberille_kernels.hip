@@ -332,13 +332,15 @@ constexpr int COUNT_WB = 2048;
 
 __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const int *__restrict__ alias, Grid g,
                                                size_t nwords, u32 *__restrict__ prefix, u64 *__restrict__ segV,
-                                               u64 *__restrict__ segQ) {
+                                               u64 *__restrict__ segQ, u32 *__restrict__ vqueue,
+                                               Totals *__restrict__ tot) {
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
-  __shared__ unsigned short queue[COUNT_WB];
-  __shared__ int nQueued;
+  __shared__ unsigned short queue[COUNT_WB], vlist[COUNT_WB];
+  __shared__ int nQueued, nVertexWords;
+  __shared__ u32 vbase;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
-  if (tid == 0) nQueued = 0;
+  if (tid == 0) { nQueued = 0; nVertexWords = 0; }
   __syncthreads();
   for (int i = tid; i < COUNT_WB; i += 256) {
     const size_t gi = w0 + i;
@@ -367,8 +369,17 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
 #pragma unroll
     for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
     cnt[i] |= (u32)nV;
+    // words that create vertices go to the global vertex-word queue (the point pass runs one lane per
+    // such word)
+    if (nV && vqueue) vlist[atomicAdd(&nVertexWords, 1)] = (unsigned short)i;
   }
   __syncthreads();
+  if (vqueue) {
+    const int nvw = nVertexWords;
+    if (tid == 0 && nvw) vbase = atomicAdd(&tot->nVertexWords, (u32)nvw);   // one global atomic per block
+    __syncthreads();
+    for (int j = tid; j < nvw; j += 256) vqueue[vbase + j] = (u32)(w0 + vlist[j]);
+  }
   for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
     const size_t gi = w0 + sg * 64 + lane;
     if ((gi & ~(size_t)63) >= nwords) break;    // wave-uniform
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(256) void k_heads(const u32 *__restrict__ prefix, c
   const u32 nextV = last ? (u32)segV[seg] : (prefix[gi + 1] & 0xffffu);
   const u32 nextQ = last ? (u32)segQ[seg] : (prefix[gi + 1] >> 16);
   const u32 cV = nextV - (p & 0xffffu), cQ = nextQ - (p >> 16);
-  if (cV) {
+  if (cV && headV) {
     const u64 b = segBaseV[seg] + (p & 0xffffu);
     for (u64 m = (b + 63) & ~63ull; m < b + cV; m += 64) headV[m >> 6] = (u32)gi;
   }
@@ -723,6 +734,43 @@ __global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Ge
   float *dst = a.points + 3 * v;
   dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
   if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
+}
+
+// K3a, queue form: one lane per word that creates vertices (the queue k_count left, dense in lanes and
+// unordered: a word's vertex ids follow from its own prefix).  The word is classified ONCE and the lane
+// walks its created corners in id order -- voxel by voxel, corner 0..7 -- writing the lattice points
+// and the dense corner map.  Lanes of a wave write neighbouring id ranges.
+__global__ __launch_bounds__(256) void k_emit_points_queue(EmitArgs a, Grid g, Geo geo, const u32 *__restrict__ vqueue,
+                                                           u32 nVertexWords) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nVertexWords) return;
+  const size_t gi = vqueue[t];
+  const size_t row = gi / g.W;
+  const int k = (int)(gi % g.W);
+  const int y = (int)(row % g.ny);
+  const int z = g.cz0 + (int)(row / g.ny);
+  WordInfo w;
+  classify_word(a.bits, a.alias, g, y, z, k, w);
+  u64 v = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);       // id of this word's first vertex
+  u64 any = w.C[0] | w.C[1] | w.C[2] | w.C[3] | w.C[4] | w.C[5] | w.C[6] | w.C[7];
+  while (any) {
+    const int bx = __ffsll((long long)any) - 1;
+    any &= any - 1;
+    unsigned cm = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
+    while (cm) {
+      const int e = kCornerEnc[__ffs((int)cm) - 1];
+      cm &= cm - 1;
+      const int cx = k * 64 + bx + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
+      float p[3];
+      corner_point(geo, cx, cy, g.zglob0 + cz, p);
+      float *dst = a.points + 3 * v;
+      dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+      if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
+      v++;
+    }
+  }
 }
 
 // the six face masks of a word only (7 bit-rows instead of 27)
@@ -1230,7 +1278,8 @@ hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s
 
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
-  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.alias, g, nwords, w.prefix, w.segV, w.segQ);
+  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.alias, g, nwords, w.prefix, w.segV, w.segQ,
+                     nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
   return hipGetLastError();
 }
 
@@ -1245,7 +1294,7 @@ hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, si
 }
 
 hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s) {
-  if (!w.headV || !w.headQ) return hipSuccess;
+  if (!w.headQ) return hipSuccess;
   hipLaunchKernelGGL(k_heads, dim3(grid_for(nwords, 256, 0)), dim3(256), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ,
                      nwords, w.headV, w.headQ);
   return hipGetLastError();
@@ -1269,11 +1318,14 @@ static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
   return a;
 }
 
-hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, hipStream_t s) {
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s) {
   if (!nV) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 1;
-  if (w.headV && variant == 1) {
+  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 2;
+  if (w.vqueue && nwords < 0xffffffffULL && variant == 2) {
+    hipLaunchKernelGGL(k_emit_points_queue, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo,
+                       w.vqueue, nVertexWords);
+  } else if (w.headV && variant >= 1) {
     const size_t nseg = (nwords + 63) >> 6;
     hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo, nseg, nwords, nV);
   } else {

@@ -321,7 +321,7 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world):
     assert_same_mesh(m, ref)
 
 
-@pytest.mark.parametrize("env", ["CUBERILLE_NO_CMAP", "CUBERILLE_NO_HEADS"])
+@pytest.mark.parametrize("env", ["CUBERILLE_NO_CMAP", "CUBERILLE_NO_HEADS", "CUBERILLE_NO_VQUEUE"])
 def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, monkeypatch, env):
     """When the dense corner map (4 B per lattice corner) or the head tables cannot be allocated the
     kernels recompute ids / search the prefix arrays instead; same mesh either way."""
