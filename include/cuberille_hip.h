@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 1
+#define CUBERILLE_ABI_VERSION 2
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -82,6 +82,8 @@ typedef struct {
   int64_t own_z0, own_z1;   /* global slices [own_z0, own_z1) this rank emits */
   uint64_t point_id_offset; /* ids of this rank's first point / first cell; set them */
   uint64_t cell_id_offset;  /*   with cuberille_emit after the count all-gather */
+  void *halo_ready_event;   /* optional hipEvent_t recorded behind the halo exchange: cuberille_count
+                               thresholds the owned slices at once and the halo slices after it */
 } cuberille_slab;
 
 typedef struct {

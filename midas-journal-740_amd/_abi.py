@@ -36,7 +36,7 @@ class Params(C.Structure):
 
 class Slab(C.Structure):
     _fields_ = [("global_nz", C.c_int64), ("z_begin", C.c_int64), ("own_z0", C.c_int64), ("own_z1", C.c_int64),
-                ("point_id_offset", C.c_uint64), ("cell_id_offset", C.c_uint64)]
+                ("point_id_offset", C.c_uint64), ("cell_id_offset", C.c_uint64), ("halo_ready_event", C.c_void_p)]
 
 
 class Result(C.Structure):

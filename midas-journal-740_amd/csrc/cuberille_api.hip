@@ -195,7 +195,7 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   g.nx = (int)img->dims[0]; g.ny = (int)img->dims[1]; g.nzb = (int)img->dims[2];
   g.W = (g.nx + 63) / 64;
   g.lastpos = (g.nx - 1) & 63;
-  const bool whole = !slab || (slab->global_nz == 0 && slab->z_begin == 0 && slab->own_z0 == 0 && slab->own_z1 == 0);
+  const bool whole = !slab || (slab->global_nz == 0 && slab->z_begin == 0 && slab->own_z0 == 0 && slab->own_z1 == 0);   // (all-zero slab = whole volume)
   if (whole) {
     g.gnz = g.nzb; g.zglob0 = 0; g.oz0 = 0; g.oz1 = g.nzb;
   } else {
@@ -269,7 +269,16 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   HIP_TRY(c, hipMemsetAsync(w.sliceOcc, 0, (size_t)g.nzb * sizeof(u32), s));
   HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals), s));
   HIP_TRY(c, hipEventRecord(c->ev[0], s));
-  HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, s));
+  if (!whole && slab->halo_ready_event && (g.oz0 > 0 || g.oz1 < g.nzb)) {
+    // the caller's halo exchange is still in flight: threshold the owned slices now, the halo
+    // slices once the event it recorded behind the exchange has fired
+    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, g.oz0, g.oz1, s));
+    HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->halo_ready_event, 0));
+    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, 0, g.oz0, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, g.oz1, g.nzb, s));
+  } else {
+    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, 0, g.nzb, s));
+  }
   HIP_TRY(c, hipEventRecord(c->ev[1], s));
   HIP_TRY(c, launch_alias(w, g, p.q1, s));
   HIP_TRY(c, launch_count(w, g, nwords, s));

@@ -71,7 +71,7 @@ struct Params {
 };
 
 // launchers (cuberille_kernels.hip); all asynchronous on `s`
-hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, hipStream_t s);
+hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, int z0, int z1, hipStream_t s);
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s);
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s);

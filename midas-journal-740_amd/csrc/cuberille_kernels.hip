@@ -1226,11 +1226,16 @@ static int occupancy_shift(const Grid &g) {
   return lg;
 }
 
-hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, hipStream_t s) {
+// classify slices [z0, z1) of the buffer (a z-range is a contiguous range of voxels and of words)
+hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, double iso, int z0, int z1, hipStream_t s) {
+  if (z1 <= z0) return hipSuccess;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
-    const T *vox = (const T *)w.vox;
-    const u64 nrows = (u64)g.ny * g.nzb;
+    Workspace w = wAll;
+    const T *vox = (const T *)wAll.vox + (size_t)z0 * g.ny * g.nx;
+    w.bits = wAll.bits + (size_t)z0 * g.ny * g.W;
+    w.sliceOcc = wAll.sliceOcc + z0;
+    const u64 nrows = (u64)g.ny * (z1 - z0);
     const bool aligned = ((uintptr_t)vox % 16) == 0;
     if (g.nx % 64 == 0 && aligned) {
       constexpr int VPL = 16 / sizeof(T);

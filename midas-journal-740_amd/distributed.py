@@ -33,9 +33,10 @@ def buffer_range(global_nz, z0, z1, halo=HALO):
     return max(z0 - halo, 0), min(z1 + halo, int(global_nz))
 
 
-def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None):
+def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
-    Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together."""
+    Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together.
+    wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
     import torch.distributed as dist
     if buf.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
@@ -65,9 +66,11 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None):
             t = buf[z0 - lo:z0 - lo + n].contiguous()
             keep.append(t)
             ops.append(dist.P2POp(dist.isend, t, rank - 1, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:
+        return reqs, keep
+    for req in reqs:
+        req.wait()
     return buf
 
 
@@ -123,7 +126,8 @@ class ShardedExtractor:
         if world > 1 and self.z1 - self.z0 < HALO:
             raise ValueError("slabs thinner than the halo (%d slices) are not supported" % HALO)
         self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
-        self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0)
+        self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None)
+        self._halo_event = None
         self.check_aliasing = check_aliasing
         self.counts = None
 
@@ -132,11 +136,27 @@ class ShardedExtractor:
         count, the count all-gather and emit; leaves this rank's mesh part on its device."""
         import torch
         import torch.distributed as dist
+        keep = None
         if self.world > 1:
-            exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group)
-            if buf.is_cuda:
-                torch.cuda.current_stream().synchronize()
+            if buf.is_cuda and dist.get_backend(self.group) == "nccl":
+                # RCCL: do not wait on the host.  req.wait() only orders torch's current stream behind the
+                # transfer; an event recorded there tells the library when the halo slices are in, and it
+                # thresholds the owned slices meanwhile.
+                reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
+                                            wait=False)
+                for req in reqs:
+                    req.wait()
+                if self._halo_event is None:
+                    self._halo_event = torch.cuda.Event()
+                self._halo_event.record(torch.cuda.current_stream())
+                self.slab.halo_ready_event = self._halo_event.cuda_event
+            else:
+                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group)
+                if buf.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                self.slab.halo_ready_event = None
         n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab if self.world > 1 else None)
+        del keep
         if self.world > 1:
             self.counts = gather_counts(n_p, n_c, buf.device, self.group)
             poff, coff = id_offsets(self.counts, self.rank)

@@ -412,3 +412,38 @@ def test_1024_marschner_lobb_properties(pkg, extractor):
         poff += n_p
     assert np.array_equal(np.concatenate(cells), tri.cells)
     assert np.array_equal(np.concatenate(pts).view(np.uint32), tri.points.view(np.uint32))
+
+
+def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, volumes):
+    """cuberille_slab.halo_ready_event: the halo slices of the buffer are still being written (here by a
+    copy on a side stream, in production by the RCCL exchange) when cuberille_count is called; the library
+    thresholds the owned slices first and the halo slices only after the event."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    prm = pkg.make_params(85, **kw)
+    full = torch.from_numpy(vol.voxels).cuda()
+    side = torch.cuda.Stream()
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 14), (14, 29), (29, 40)]:
+        lo, hi = max(a - 8, 0), min(b + 8, nz)
+        buf = torch.full((hi - lo, ny, nx), 255, dtype=torch.uint8, device="cuda")     # wrong halo content
+        buf[a - lo:b - lo] = full[a:b]
+        torch.cuda.synchronize()
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(20_000_000)                                                # the "exchange" takes a while
+            buf[:a - lo] = full[lo:a]
+            buf[b - lo:] = full[b:hi]
+            ev.record(side)
+        desc = pkg.make_desc(np.uint8, (nx, ny, hi - lo))
+        slab = pkg._abi.Slab(nz, lo, a, b, 0, 0, ev.cuda_event)
+        n_p, n_c = extractor.count(buf.data_ptr(), desc, prm, slab)
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)

@@ -23,13 +23,13 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == 1
+    assert lib.cuberille_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(pkg):
     assert C.sizeof(pkg._abi.ImageDesc) == 8 + 24 + 24 + 24 + 72
     assert C.sizeof(pkg._abi.Params) == 8 + 8 + 8 + 8 + 8 + 8
-    assert C.sizeof(pkg._abi.Slab) == 48
+    assert C.sizeof(pkg._abi.Slab) == 56
     assert C.sizeof(pkg._abi.Result) == 8 + 8 + 8 + 7 * 4 + 4 + 8
 
 
