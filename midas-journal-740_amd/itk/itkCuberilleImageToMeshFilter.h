@@ -34,59 +34,59 @@ template <class TInputImage, class TOutputMesh,
 class ITK_EXPORT CuberilleImageToMeshFilter : public ImageToMeshFilter<TInputImage, TOutputMesh>
 {
 public:
-  typedef CuberilleImageToMeshFilter                  Self;
+  typedef CuberilleImageToMeshFilter Self;
   typedef ImageToMeshFilter<TInputImage, TOutputMesh> Superclass;
-  typedef SmartPointer<Self>                          Pointer;
-  typedef SmartPointer<const Self>                    ConstPointer;
+  typedef SmartPointer<Self> Pointer;
+  typedef SmartPointer<const Self> ConstPointer;
 
   itkNewMacro(Self);
   itkTypeMacro(CuberilleImageToMeshFilter, ImageToMeshFilter);
 
   // -- output side (reference h:127-145) --
-  typedef TOutputMesh                                      OutputMeshType;
-  typedef typename OutputMeshType::Pointer                 OutputMeshPointer;
-  typedef typename OutputMeshType::MeshTraits              OutputMeshTraits;
-  typedef typename OutputMeshType::PointType               OutputPointType;
-  typedef typename OutputMeshType::PointType               PointType;
-  typedef typename OutputMeshTraits::PixelType             OutputPixelType;
-  typedef typename OutputMeshType::CellTraits              CellTraits;
-  typedef typename OutputMeshType::PointsContainer         PointsContainer;
-  typedef typename OutputMeshType::PointsContainerPointer  PointsContainerPointer;
-  typedef typename OutputMeshType::CellsContainer          CellsContainer;
-  typedef typename OutputMeshType::CellsContainerPointer   CellsContainerPointer;
-  typedef typename OutputMeshType::PointIdentifier         PointIdentifier;
-  typedef typename OutputMeshType::CellIdentifier          CellIdentifier;
-  typedef CellInterface<OutputPixelType, CellTraits>       CellInterfaceType;
-  typedef TriangleCell<CellInterfaceType>                  TriangleCellType;
-  typedef typename TriangleCellType::SelfAutoPointer       TriangleAutoPointer;
-  typedef typename TriangleCellType::CellAutoPointer       TriangleCellAutoPointer;
-  typedef QuadrilateralCell<CellInterfaceType>             QuadrilateralCellType;
-  typedef typename QuadrilateralCellType::SelfAutoPointer  QuadrilateralAutoPointer;
-  typedef typename QuadrilateralCellType::CellAutoPointer  QuadrilateralCellAutoPointer;
+  typedef TOutputMesh OutputMeshType;
+  typedef typename OutputMeshType::Pointer OutputMeshPointer;
+  typedef typename OutputMeshType::MeshTraits OutputMeshTraits;
+  typedef typename OutputMeshType::PointType OutputPointType;
+  typedef typename OutputMeshType::PointType PointType;
+  typedef typename OutputMeshTraits::PixelType OutputPixelType;
+  typedef typename OutputMeshType::CellTraits CellTraits;
+  typedef typename OutputMeshType::PointsContainer PointsContainer;
+  typedef typename OutputMeshType::PointsContainerPointer PointsContainerPointer;
+  typedef typename OutputMeshType::CellsContainer CellsContainer;
+  typedef typename OutputMeshType::CellsContainerPointer CellsContainerPointer;
+  typedef typename OutputMeshType::PointIdentifier PointIdentifier;
+  typedef typename OutputMeshType::CellIdentifier CellIdentifier;
+  typedef CellInterface<OutputPixelType, CellTraits> CellInterfaceType;
+  typedef TriangleCell<CellInterfaceType> TriangleCellType;
+  typedef typename TriangleCellType::SelfAutoPointer TriangleAutoPointer;
+  typedef typename TriangleCellType::CellAutoPointer TriangleCellAutoPointer;
+  typedef QuadrilateralCell<CellInterfaceType> QuadrilateralCellType;
+  typedef typename QuadrilateralCellType::SelfAutoPointer QuadrilateralAutoPointer;
+  typedef typename QuadrilateralCellType::CellAutoPointer QuadrilateralCellAutoPointer;
 
   // -- input side (reference h:147-159) --
-  typedef TInputImage                               InputImageType;
-  typedef typename InputImageType::Pointer          InputImagePointer;
-  typedef typename InputImageType::ConstPointer     InputImageConstPointer;
-  typedef typename InputImageType::PixelType        InputPixelType;
-  typedef typename InputImageType::SizeType         SizeType;
-  typedef typename InputImageType::SpacingType      SpacingType;
+  typedef TInputImage InputImageType;
+  typedef typename InputImageType::Pointer InputImagePointer;
+  typedef typename InputImageType::ConstPointer InputImageConstPointer;
+  typedef typename InputImageType::PixelType InputPixelType;
+  typedef typename InputImageType::SizeType SizeType;
+  typedef typename InputImageType::SpacingType SpacingType;
   typedef typename InputImageType::SpacingValueType SpacingValueType;
-  typedef typename InputImageType::IndexType        IndexType;
-  typedef TInterpolator                             InterpolatorType;
-  typedef typename InterpolatorType::Pointer        InterpolatorPointer;
-  typedef typename InterpolatorType::OutputType     InterpolatorOutputType;
+  typedef typename InputImageType::IndexType IndexType;
+  typedef TInterpolator InterpolatorType;
+  typedef typename InterpolatorType::Pointer InterpolatorPointer;
+  typedef typename InterpolatorType::OutputType InterpolatorOutputType;
 
   // -- names the reference exposes for its CPU internals (h:162-173); kept so user code that
   //    mentions them still compiles, unused by the GPU path --
-  typedef ConstShapedNeighborhoodIterator<InputImageType>              InputImageIteratorType;
-  typedef GradientImageFilter<InputImageType>                          GradientFilterType;
-  typedef typename GradientFilterType::Pointer                         GradientFilterPointer;
-  typedef typename GradientFilterType::OutputImageType                 GradientImageType;
-  typedef typename GradientImageType::Pointer                          GradientImagePointer;
-  typedef typename GradientFilterType::OutputPixelType                 GradientPixelType;
+  typedef ConstShapedNeighborhoodIterator<InputImageType> InputImageIteratorType;
+  typedef GradientImageFilter<InputImageType> GradientFilterType;
+  typedef typename GradientFilterType::Pointer GradientFilterPointer;
+  typedef typename GradientFilterType::OutputImageType GradientImageType;
+  typedef typename GradientImageType::Pointer GradientImagePointer;
+  typedef typename GradientFilterType::OutputPixelType GradientPixelType;
   typedef itk::VectorLinearInterpolateImageFunction<GradientImageType> GradientInterpolatorType;
-  typedef typename GradientInterpolatorType::Pointer                   GradientInterpolatorPointer;
+  typedef typename GradientInterpolatorType::Pointer GradientInterpolatorPointer;
 
   /** Iso-surface value: pixels >= this value are inside (reference h:180-181, txx:139-141). */
   itkGetMacro(IsoSurfaceValue, InputPixelType);
@@ -138,17 +138,17 @@ private:
   CuberilleImageToMeshFilter(const Self &);   // not implemented
   void operator=(const Self &);               // not implemented
 
-  InputPixelType      m_IsoSurfaceValue;
+  InputPixelType m_IsoSurfaceValue;
   InterpolatorPointer m_Interpolator;
-  SpacingValueType    m_MaxSpacing;
-  bool                m_GenerateTriangleFaces;
-  bool                m_ProjectVerticesToIsoSurface;
-  double              m_ProjectVertexSurfaceDistanceThreshold;
-  double              m_ProjectVertexStepLength;
-  double              m_ProjectVertexStepLengthRelaxationFactor;
-  unsigned int        m_ProjectVertexMaximumNumberOfSteps;
-  int                 m_Device;
-  double              m_LastDeviceSeconds;
+  SpacingValueType m_MaxSpacing;
+  bool m_GenerateTriangleFaces;
+  bool m_ProjectVerticesToIsoSurface;
+  double m_ProjectVertexSurfaceDistanceThreshold;
+  double m_ProjectVertexStepLength;
+  double m_ProjectVertexStepLengthRelaxationFactor;
+  unsigned int m_ProjectVertexMaximumNumberOfSteps;
+  int m_Device;
+  double m_LastDeviceSeconds;
   ::cuberille_ctx    *m_Context;
 };
 
