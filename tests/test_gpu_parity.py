@@ -447,3 +447,41 @@ def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, vol
         cells.append(m.cells)
         poff += n_p
     assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def test_fuzz_shapes_types_parameters(pkg, oracle, extractor):
+    """120 seeded random cases: degenerate and ragged shapes (1-thick volumes, nx around the 64-voxel word
+    and the 1 KiB load granule), every pixel type, sparse to dense occupancy, blanked slices (quirk Q1),
+    random spacing/origin, quads/triangles, projection on/off with random knobs."""
+    rng = np.random.default_rng(20261003)
+    dtypes = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64]
+    xs = [1, 2, 3, 31, 63, 64, 65, 127, 128, 129, 191, 192, 256, 257, 300]
+    for case in range(120):
+        nx = int(rng.choice(xs))
+        ny = int(rng.integers(1, 9))
+        nz = int(rng.integers(1, 9))
+        dt = dtypes[case % len(dtypes)]
+        dens = float(rng.choice([0.02, 0.2, 0.5, 0.9]))
+        smooth = rng.random((nz, ny, nx))
+        if np.dtype(dt).kind == "f":
+            vox = (smooth - (1.0 - dens)).astype(dt)
+            iso = 0.0
+        else:
+            hi = 100
+            vox = np.where(smooth < dens, hi, 0).astype(dt) + rng.integers(0, 20, size=smooth.shape).astype(dt)
+            iso = 50
+        if rng.random() < 0.3 and nz > 2:
+            vox[rng.integers(0, nz)] = vox.min()                      # an empty slice
+        kw = dict(triangles=bool(rng.integers(0, 2)), project=bool(rng.integers(0, 2)),
+                  threshold=float(rng.choice([0.01, 0.2, 5.0])), step=float(rng.choice([-1.0, 0.1, 0.25, 0.6])),
+                  relax=float(rng.choice([0.5, 0.95, 1.0])), max_steps=int(rng.choice([0, 3, 50])))
+        spacing = tuple(float(v) for v in rng.choice([0.5, 1.0, 1.7], size=3))
+        origin = tuple(float(v) for v in rng.normal(0, 5, size=3).round(3))
+        vol = pkg.Volume(vox, spacing=spacing, origin=origin)
+        mesh = run_gpu(pkg, extractor, vol, iso, **kw)
+        ref = oracle.run(vox, iso, spacing=spacing, origin=origin, **kw)
+        try:
+            assert_same_mesh(mesh, ref)
+        except AssertionError as e:
+            raise AssertionError("case %d: shape %s dtype %s %s spacing %s: %s" % (
+                case, vox.shape, np.dtype(dt).name, kw, spacing, e))
