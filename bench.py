@@ -138,7 +138,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     pkg = graft.load_package()
-    pkg._abi.build()
+    # the library is built by __graft_entry__.build(); here only make sure it exists, and never let
+    # several ranks run the compiler on the same output at once
+    if not os.path.exists(pkg._abi.LIB_PATH):
+        if local_rank == 0:
+            pkg._abi.build()
+        if world > 1:
+            dist.barrier()
     from midas_journal_740_amd.distributed import ShardedExtractor
 
     n = args.size
