@@ -1,0 +1,97 @@
+// Instantiates the drop-in filter for pixel types other than the reference driver's unsigned char
+// ("template must still compile for other pixel types") and runs each on a small
+// synthetic sphere.  Prints one line per instantiation: "<type> points cells euler"; exit code 0 if every
+// mesh is a closed genus-0 surface (V - E + F = 2 for quads) with the same topology for every type.
+#include <cmath>
+#include <iostream>
+#include <set>
+#include <utility>
+
+#include "itkImage.h"
+#include "itkMesh.h"
+#include "itkCuberilleImageToMeshFilter.h"
+
+template <class TPixel>
+bool run(const char *name, bool triangles, unsigned long &points, unsigned long &cells)
+{
+  typedef itk::Image<TPixel, 3> ImageType;
+  typedef itk::Mesh<float, 3> MeshType;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType> FilterType;
+  const int n = 40;
+  typename ImageType::Pointer image = ImageType::New();
+  typename ImageType::RegionType region;
+  typename ImageType::IndexType start;
+  typename ImageType::SizeType size;
+  start.Fill(0);
+  size.Fill(n);
+  region.SetIndex(start);
+  region.SetSize(size);
+  image->SetRegions(region);
+  image->Allocate();
+  typename ImageType::SpacingType spacing;
+  spacing[0] = 0.5; spacing[1] = 1.0; spacing[2] = 2.0;
+  image->SetSpacing(spacing);
+  for (int z = 0; z < n; z++)
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++)
+        {
+        typename ImageType::IndexType idx;
+        idx[0] = x; idx[1] = y; idx[2] = z;
+        const double r = std::sqrt((x - 19.3) * (x - 19.3) + (y - 19.6) * (y - 19.6) + (z - 19.1) * (z - 19.1));
+        const double v = 100.0 - 6.0 * r;                            // 100 at the centre, clamped at 0 far out
+        image->SetPixel(idx, static_cast<TPixel>(v > 0.0 ? v : 0.0));
+        }
+  typename FilterType::Pointer filter = FilterType::New();
+  filter->SetInput(image);
+  filter->SetIsoSurfaceValue(static_cast<TPixel>(30));
+  filter->SetGenerateTriangleFaces(triangles);
+  filter->SetProjectVertexSurfaceDistanceThreshold(0.5);
+  filter->Update();
+  typename MeshType::Pointer mesh = filter->GetOutput();
+  points = mesh->GetNumberOfPoints();
+  cells = mesh->GetNumberOfCells();
+  std::set<std::pair<unsigned long, unsigned long> > edges;
+  for (unsigned long c = 0; c < cells; c++)
+    {
+    typename MeshType::CellAutoPointer cell;
+    mesh->GetCell(c, cell);
+    const unsigned int k = cell->GetNumberOfPoints();
+    typename MeshType::CellType::PointIdConstIterator it = cell->PointIdsBegin();
+    for (unsigned int i = 0; i < k; i++)
+      {
+      unsigned long a = it[i], b = it[(i + 1) % k];
+      if (a > b) std::swap(a, b);
+      edges.insert(std::make_pair(a, b));
+      }
+    }
+  const long euler = (long)points - (long)edges.size() + (long)cells;
+  std::cout << name << " " << points << " " << cells << " " << euler << std::endl;
+  return euler == 2 && points > 0;
+}
+
+int main()
+{
+  try
+    {
+    bool ok = true;
+    unsigned long p[6], c[6];
+    ok &= run<unsigned char>("uchar", false, p[0], c[0]);
+    ok &= run<short>("short", false, p[1], c[1]);
+    ok &= run<unsigned short>("ushort", false, p[2], c[2]);
+    ok &= run<int>("int", false, p[3], c[3]);
+    ok &= run<float>("float", false, p[4], c[4]);
+    ok &= run<double>("double", false, p[5], c[5]);
+    // value >= 30 is the same set of voxels whether the field is truncated to an integer or not:
+    // identical topology for every pixel type
+    for (int i = 1; i < 6; i++) ok &= (p[i] == p[0]) && (c[i] == c[0]);
+    unsigned long pt, ct;
+    ok &= run<float>("float-triangles", true, pt, ct);
+    ok &= (pt == p[4]) && (ct == 2 * c[4]);
+    return ok ? 0 : 1;
+    }
+  catch (itk::ExceptionObject &e)
+    {
+    std::cerr << e << std::endl;
+    return 2;
+    }
+}

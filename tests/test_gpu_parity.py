@@ -485,3 +485,18 @@ def test_fuzz_shapes_types_parameters(pkg, oracle, extractor):
         except AssertionError as e:
             raise AssertionError("case %d: shape %s dtype %s %s spacing %s: %s" % (
                 case, vox.shape, np.dtype(dt).name, kw, spacing, e))
+
+
+def test_cxx_dropin_instantiates_for_other_pixel_types():
+    """itk/tests/instantiations.cxx: the filter template instantiated for uchar/short/ushort/int/float/double
+    images (and a float mesh) through the C ABI; each mesh must be a closed genus-0 quad surface."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "instantiations")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(os.path.dirname(exe)), "build/instantiations"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr[-500:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 7 and all(l.split()[3] == "2" for l in lines)
