@@ -500,3 +500,37 @@ def test_cxx_dropin_instantiates_for_other_pixel_types():
     assert r.returncode == 0, (r.stdout, r.stderr[-500:])
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 7 and all(l.split()[3] == "2" for l in lines)
+
+
+def test_noise_u8_config5_properties(pkg, extractor):
+    """BASELINE.json configs[4] (uint8 gradient noise, iso 128) at 512^3 on one GPU: counts equal the closed
+    form, the flat classify path for 1-byte pixels (SWAR compare) agrees with a plain threshold, and the
+    8-slab decomposition (what 8 ranks would do) reproduces the single-shot buffers bit for bit."""
+    import torch
+    n = 512
+    vol = torch.cat([pkg.volumes.gradient_noise(n, n, n, a, min(a + 64, n), xp=torch, device="cuda") for a in range(0, n, 64)])
+    desc = pkg.make_desc(np.uint8, (n, n, n))
+    want_pts, want_quads = _closed_form_counts_torch(vol >= 128)
+    prm = pkg.make_params(128, triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+    extractor.extract_device(vol.data_ptr(), desc, prm)
+    whole = extractor.download()
+    assert (whole.GetNumberOfPoints(), whole.GetNumberOfCells()) == (want_pts, 2 * want_quads)
+    words = extractor.debug_bits((n, n, n))
+    bits = torch.from_numpy(words.view(np.int64)).cuda()
+    shifts = torch.arange(64, device="cuda", dtype=torch.int64)
+    unpacked = ((bits[..., None] >> shifts) & 1).bool().reshape(n, n, n)
+    assert bool((unpacked == (vol >= 128)).all())
+    del bits, unpacked
+    pts, cells, poff = [], [], 0
+    for r in range(8):
+        a, b = r * 64, (r + 1) * 64
+        lo, hi = max(a - 8, 0), min(b + 8, n)
+        slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
+        n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (n, n, hi - lo)), prm, slab)
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert np.array_equal(np.concatenate(cells), whole.cells)
+    assert np.array_equal(np.concatenate(pts).view(np.uint32), whole.points.view(np.uint32))
