@@ -347,13 +347,18 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     u32 packed = 0;
     if (gi < nwords) {
       const size_t row = gi / g.W;
-      u64 F[6];
-      faces_word(bits, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), F);
-      int nQ = 0;
+      const int y = (int)(row % g.ny), z = g.cz0 + (int)(row / g.ny);
+      // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
+      // whole runs of such words, so whole waves take the short way)
+      if (bits[((size_t)z * g.ny + y) * g.W + gi % g.W] != 0) {
+        u64 F[6];
+        faces_word(bits, g, y, z, (int)(gi % g.W), F);
+        int nQ = 0;
 #pragma unroll
-      for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
-      packed = (u32)nQ << 16;
-      if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
+        for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
+        packed = (u32)nQ << 16;
+        if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
+      }
     }
     cnt[i] = packed;
   }
