@@ -37,8 +37,9 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
     Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together.
     wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
+    import os
     import torch.distributed as dist
-    if buf.is_cuda and dist.get_backend(group) == "gloo":
+    if buf.is_cuda and dist.get_backend(group) == "gloo" and wait:
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
         host = buf.cpu()
         exchange_halos(host, lo, hi, z0, z1, rank, world, group)
@@ -134,11 +135,13 @@ class ShardedExtractor:
     def extract(self, buf, params):
         """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid.  Runs halo exchange,
         count, the count all-gather and emit; leaves this rank's mesh part on its device."""
+        import os
         import torch
         import torch.distributed as dist
         keep = None
         if self.world > 1:
-            if buf.is_cuda and dist.get_backend(self.group) == "nccl":
+            # (CUBERILLE_FORCE_EVENT_PATH: take this branch under gloo too -- test hook for one-GPU boxes)
+            if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or os.environ.get("CUBERILLE_FORCE_EVENT_PATH")):
                 # RCCL: do not wait on the host.  req.wait() only orders torch's current stream behind the
                 # transfer; an event recorded there tells the library when the halo slices are in, and it
                 # thresholds the owned slices meanwhile.

@@ -266,8 +266,10 @@ def test_reference_driver_unchanged(oracle, volumes, ctest_cases, tmp_path):
     assert r.returncode != 0 and "Expected mesh with 9 points" in r.stderr
 
 
-def _rank_worker(rank, world, port, name, iso, out_dir):
+def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
     import os
+    if event_path:
+        os.environ["CUBERILLE_FORCE_EVENT_PATH"] = "1"
     import sys
     import torch
     import torch.distributed as dist
@@ -296,11 +298,12 @@ def _rank_worker(rank, world, port, name, iso, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world):
+@pytest.mark.parametrize("world,event_path", [(2, False), (3, False), (2, True)])
+def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
-    the concatenation of the rank meshes must be the oracle's mesh of the whole volume."""
+    the concatenation of the rank meshes must be the oracle's mesh of the whole volume.  event_path: the
+    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo)."""
     import socket
     import torch.multiprocessing as mp
     name, iso = "silicium.mha", 85
@@ -308,7 +311,7 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path), nprocs=world, join=True)
     pts = np.concatenate([np.load(str(tmp_path / ("p%d.npy" % r))) for r in range(world)])
     cells = np.concatenate([np.load(str(tmp_path / ("c%d.npy" % r))) for r in range(world)])
     ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95,
