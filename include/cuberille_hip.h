@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 2
+#define CUBERILLE_ABI_VERSION 3
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -135,6 +135,16 @@ int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, uint64_t cell_i
  * points = float[3*n_points], cells = uint64[verts_per_cell*n_cells] holding GLOBAL point ids. */
 int cuberille_mesh_device(const cuberille_ctx *ctx, const float **d_points, const uint64_t **d_cells);
 int cuberille_mesh_download(cuberille_ctx *ctx, float *points, uint64_t *cells);
+
+/* Flat-mesh file output (replaces the itk::Mesh fill + itk::VTKPolyDataWriter pass of
+ * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA,
+ * byte-identical to what that writer produces for the same mesh, formatted by `n_threads` host threads
+ * (0 = one per core, at most 32).  The first form writes host buffers and needs no GPU (multi-GPU: rank 0
+ * passes the rank-ordered concatenation, whose ids are already global); the second downloads the context's
+ * last mesh first and refuses a slab mesh (its cells reference points of the rank below). */
+int cuberille_write_vtk_buffers(const char *path, const float *points, uint64_t n_points,
+                                const uint64_t *cells, uint64_t n_cells, int verts_per_cell, int n_threads);
+int cuberille_mesh_write_vtk(cuberille_ctx *ctx, const char *path, int n_threads);
 
 /* Introspection used by the parity tests: copy the packed inside-bit volume of the last
  * count ((Nx+63)/64 uint64 words per x-row, rows in (z,y) raster order) to `words`. */

@@ -19,7 +19,7 @@ EXPORTS = [
     "cuberille_abi_version", "cuberille_device_count", "cuberille_last_error", "cuberille_create",
     "cuberille_destroy", "cuberille_set_stream", "cuberille_extract_host", "cuberille_extract_device",
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
-    "cuberille_debug_bits", "cuberille_slice_occupancy",
+    "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
 ]
 
 
@@ -57,7 +57,7 @@ class CuberilleError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/*.hip for gfx950 with hipcc (works without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("cuberille_kernels.hip", "cuberille_api.hip", "cuberille_internal.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("cuberille_kernels.hip", "cuberille_api.hip", "cuberille_vtk.cpp", "cuberille_internal.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "cuberille_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
@@ -102,6 +102,8 @@ def lib():
     L.cuberille_mesh_download.argtypes = [vp, vp, vp]
     L.cuberille_debug_bits.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_slice_occupancy.argtypes = [vp, vp, C.c_size_t]
+    L.cuberille_write_vtk_buffers.argtypes = [C.c_char_p, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int]
+    L.cuberille_mesh_write_vtk.argtypes = [vp, C.c_char_p, C.c_int]
     _lib = L
     return L
 

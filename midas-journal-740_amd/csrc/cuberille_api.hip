@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace cuberille;
 
@@ -47,7 +48,7 @@ struct cuberille_ctx {
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   // state of the last count
-  bool counted = false, haveMesh = false;
+  bool counted = false, haveMesh = false, slabMesh = false;
   Grid g{};
   Geo geo{};
   Params prm{};
@@ -310,6 +311,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit called before a successful cuberille_count");
   (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
+  c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 nV = c->tot.totV;                 // ghost + owned
   const u64 nGhost = c->tot.V0;
@@ -402,6 +404,21 @@ int cuberille_mesh_download(cuberille_ctx *c, float *points, uint64_t *cells) {
     HIP_TRY(c, hipMemcpyAsync(cells, c->cells.p, r.n_cells * r.verts_per_cell * sizeof(uint64_t),
                               hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CUBERILLE_OK;
+}
+
+int cuberille_mesh_write_vtk(cuberille_ctx *c, const char *path, int n_threads) {
+  if (!c || !path) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");
+  if (c->slabMesh) return fail(c, CUBERILLE_ERR_STATE, "a slab mesh is not self-contained: concatenate the rank buffers and call cuberille_write_vtk_buffers");
+  const cuberille_result &r = c->res;
+  std::vector<float> pts(3 * r.n_points);
+  std::vector<uint64_t> cells((size_t)r.verts_per_cell * r.n_cells);
+  const int rc = cuberille_mesh_download(c, pts.data(), cells.data());
+  if (rc != CUBERILLE_OK) return rc;
+  const int wr = cuberille_write_vtk_buffers(path, pts.data(), r.n_points, cells.data(), r.n_cells, r.verts_per_cell,
+                                             n_threads);
+  if (wr != CUBERILLE_OK) return fail(c, wr, std::string("cannot write ") + path);
   return CUBERILLE_OK;
 }
 

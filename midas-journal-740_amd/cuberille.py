@@ -10,6 +10,7 @@ driver.  Everything computes on the GPU through libcuberille_hip.so; nothing her
 falls back to a CPU implementation.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -55,6 +56,17 @@ class Mesh:
 
     def GetNumberOfCells(self):
         return int(self.cells.shape[0])
+
+    def write_vtk(self, path, threads=0):
+        """Legacy-ASCII VTK POLYDATA straight from the flat buffers (include/cuberille_hip.h:
+        cuberille_write_vtk_buffers), the bytes itk::VTKPolyDataWriter gives at CuberilleTest01.cxx:180-187."""
+        pts = np.ascontiguousarray(self.points, dtype=np.float32)
+        cells = np.ascontiguousarray(self.cells, dtype=np.uint64)
+        rc = _abi.lib().cuberille_write_vtk_buffers(os.fsencode(path), C.c_void_p(pts.ctypes.data), pts.shape[0],
+                                                    C.c_void_p(cells.ctypes.data), cells.shape[0],
+                                                    int(cells.shape[1]) if cells.ndim == 2 else 3, int(threads))
+        if rc != _abi.OK:
+            raise _abi.CuberilleError(rc, "cannot write %s" % path)
 
 
 def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50, q1=True):
@@ -146,6 +158,10 @@ class Extractor:
         _abi.check(self._ctx, self._lib.cuberille_mesh_download(
             self._ctx, C.c_void_p(pts.ctypes.data), C.c_void_p(cells.ctypes.data)))
         return Mesh(pts, cells)
+
+    def write_vtk(self, path, threads=0):
+        """Download the last whole-volume mesh and write it as legacy-ASCII VTK POLYDATA."""
+        _abi.check(self._ctx, self._lib.cuberille_mesh_write_vtk(self._ctx, os.fsencode(path), int(threads)))
 
     def device_pointers(self):
         p, c = C.c_void_p(), C.c_void_p()

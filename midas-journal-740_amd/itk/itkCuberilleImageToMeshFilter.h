@@ -125,6 +125,12 @@ public:
   itkGetMacro(Device, int);
   itkSetMacro(Device, int);
   itkGetMacro(LastDeviceSeconds, double);
+  /** Not in the reference: seconds the last GenerateData() spent pouring the flat buffers into the output
+   *  mesh (one heap cell per face, as the reference's txx:310-329 does), and a way around that cost for
+   *  callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
+   *  polydata itk::VTKPolyDataWriter would give for GetOutput(), straight from the device buffers. */
+  itkGetMacro(LastMeshFillSeconds, double);
+  void WriteLastMeshAsVTKPolyData(const char *fileName, int threads = 0);
 
 protected:
   CuberilleImageToMeshFilter();
@@ -149,6 +155,7 @@ private:
   unsigned int m_ProjectVertexMaximumNumberOfSteps;
   int m_Device;
   double m_LastDeviceSeconds;
+  double m_LastMeshFillSeconds;
   ::cuberille_ctx    *m_Context;
 };
 

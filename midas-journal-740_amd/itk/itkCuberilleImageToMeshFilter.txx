@@ -8,6 +8,7 @@
 #include "itkCuberilleImageToMeshFilter.h"
 #include "cuberille_hip.h"
 
+#include <ctime>
 #include <vector>
 
 namespace itk
@@ -45,6 +46,7 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_ProjectVertexMaximumNumberOfSteps = 50;
   m_Device = 0;
   m_LastDeviceSeconds = 0.0;
+  m_LastMeshFillSeconds = 0.0;
   m_Context = 0;
 }
 
@@ -116,6 +118,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   if (cuberille_mesh_download(m_Context, &points[0], &cells[0]) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_mesh_download: " << cuberille_last_error(m_Context));
 
+  const std::clock_t fillStart = std::clock();
   // pour the flat buffers into the mesh the way the reference does element by element: points by
   // value, one heap cell per face handed to the mesh, which owns it from then on
   if (res.n_points) mesh->GetPoints()->Reserve(static_cast<PointIdentifier>(res.n_points));
@@ -149,6 +152,15 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
       mesh->SetCell(static_cast<CellIdentifier>(c), cell);
       }
     }
+  m_LastMeshFillSeconds = static_cast<double>(std::clock() - fillStart) / CLOCKS_PER_SEC;
+}
+
+template <class TInputImage, class TOutputMesh, class TInterpolator>
+void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::WriteLastMeshAsVTKPolyData(const char *fileName, int threads)
+{
+  if (!m_Context) itkExceptionMacro(<< "WriteLastMeshAsVTKPolyData: no Update() has run on this filter");
+  if (cuberille_mesh_write_vtk(m_Context, fileName, threads) != CUBERILLE_OK)
+    itkExceptionMacro(<< "cuberille_mesh_write_vtk: " << cuberille_last_error(m_Context));
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/mesh_digests.json  (fixture set 3).
+
+ORACLE output, not reference output: the reference cannot be built here (needs ITK), and its own tests pin
+nothing but the two counts of ctest_cases.json.  For every Data volume x {quads, triangles} x {projection off,
+on} (CuberilleTest01's CLI defaults otherwise: thr 0.5, step 0.25, relax 0.95, max 50; iso = the first iso the
+reference's CTest table uses for that volume) this stores the counts and SHA-256 digests of the point buffer
+(float32 bits, little endian) and of the cell buffer (uint64 ids).  The digests freeze the oracle (a later
+edit that changes any bit of any mesh fails tests/test_oracle.py) and gate the HIP path on boxes where only
+the fixtures travel.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def digest(mesh):
+    return dict(points=int(mesh.points.shape[0]), cells=int(mesh.cells.shape[0]),
+                points_sha256=hashlib.sha256(mesh.points.astype("<f4").tobytes()).hexdigest(),
+                cells_sha256=hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest())
+
+
+def main():
+    pkg, oracle = graft.load_package(), graft.load_oracle()
+    oracle.build()
+    cases = json.load(open(os.path.join(HERE, "ctest_cases.json")))
+    iso_of = {}
+    for c in cases:
+        iso_of.setdefault(c["input"], c["iso"])
+    rows = []
+    for name in sorted(iso_of):
+        vol = pkg.read_mha(os.path.join(HERE, "data", name))
+        for tri in (0, 1):
+            for proj in (0, 1):
+                kw = dict(triangles=tri, project=proj, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+                m = oracle.run(vol.voxels, iso_of[name], spacing=vol.spacing, origin=vol.origin,
+                               direction=vol.direction, **kw)
+                rows.append(dict(input=name, iso=iso_of[name], **kw, **digest(m)))
+    with open(os.path.join(HERE, "mesh_digests.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print(len(rows), "rows")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,14 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's
 known-answer table.  Bar: identical vertex ids, cell order and counts; coordinates
 bit-identical to the oracle (the north star only asks for 1e-5 relative)."""
+import json
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
-from conftest import assert_same_mesh
+from conftest import GOLDEN, ROOT, assert_same_mesh
 
 pytestmark = pytest.mark.gpu
 
@@ -229,7 +233,7 @@ def _read_vtk_polydata(path):
     return pts, cells
 
 
-def test_reference_driver_unchanged(oracle, volumes, ctest_cases, tmp_path):
+def test_reference_driver_unchanged(pkg, extractor, oracle, volumes, ctest_cases, tmp_path):
     """The reference's own CuberilleTest01.cxx, compiled UNCHANGED against the drop-in filter header
     (midas-journal-740_amd/itk; built by __graft_entry__.build() where /root/reference exists), run
     exactly as its CTest table runs it: `CuberilleTest01 Test01 <in> <out> <iso> <pts> <cells> ...`.
@@ -253,6 +257,12 @@ def test_reference_driver_unchanged(oracle, volumes, ctest_cases, tmp_path):
                          c["relax"], c["max_steps"])
         assert np.array_equal(cells, ref.cells.astype(np.int64)), c["name"]
         np.testing.assert_allclose(pts, ref.points, rtol=1e-6, atol=0)     # 9 significant digits in the file
+        # the flat-buffer writer (no itk::Mesh in between) gives the driver's file byte for byte
+        run_gpu(pkg, extractor, volumes(c["input"]), c["iso"], triangles=c["triangles"], project=c["project"],
+                threshold=c["threshold"], step=c["step"], relax=c["relax"], max_steps=c["max_steps"])
+        flat = str(tmp_path / "flat.vtk")
+        extractor.write_vtk(flat, threads=3)
+        assert open(flat, "rb").read() == open(out, "rb").read(), c["name"]
     # the example main of Source/examples.cxx takes the same arguments without the test name
     exe2 = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "Examples")
     c = ctest_cases[-1]
@@ -343,20 +353,28 @@ def _closed_form_counts_torch(ins):
     """(#points, #quads) of the closed form on a bool tensor [z,y,x] on the GPU."""
     import torch
     quads = 0
-    for ax in range(3):
-        a = ins.movedim(ax, 0)
-        quads += int((a[1:] != a[:-1]).sum())
-    p = torch.nn.functional.pad(ins[None, None].to(torch.uint8), (1, 1, 1, 1, 1, 1), mode="replicate")[0, 0].bool()
+    for z0 in range(0, ins.shape[0], 64):
+        a = ins[z0:z0 + 65]                  # one plane of overlap for the z-faces between chunks
+        quads += int((a[1:] != a[:-1]).sum()) + int((a[:64, 1:] != a[:64, :-1]).sum()) \
+            + int((a[:64, :, 1:] != a[:64, :, :-1]).sum())
     nz, ny, nx = ins.shape
-    all_in = torch.ones((nz + 1, ny + 1, nx + 1), dtype=torch.bool, device=ins.device)
-    any_in = torch.zeros_like(all_in)
-    for dz in (0, 1):
-        for dy in (0, 1):
-            for dx in (0, 1):
-                s = p[dz:dz + nz + 1, dy:dy + ny + 1, dx:dx + nx + 1]
-                all_in &= s
-                any_in |= s
-    return int((any_in & ~all_in).sum()), quads
+    points = 0
+    for c0 in range(0, nz + 1, 32):          # corner planes c0..c1-1, from voxel planes clamp(c-1), clamp(c); chunks
+        c1 = min(c0 + 32, nz + 1)            # keep every tensor far below 2^31 elements
+        zi = torch.arange(c0 - 1, c1, device=ins.device).clamp_(0, nz - 1)
+        p = ins[zi]
+        p = torch.cat([p[:, :1], p, p[:, -1:]], 1)
+        p = torch.cat([p[:, :, :1], p, p[:, :, -1:]], 2)
+        all_in = torch.ones((c1 - c0, ny + 1, nx + 1), dtype=torch.bool, device=ins.device)
+        any_in = torch.zeros_like(all_in)
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    s_ = p[dz:dz + c1 - c0, dy:dy + ny + 1, dx:dx + nx + 1]
+                    all_in &= s_
+                    any_in |= s_
+        points += int((any_in & ~all_in).sum())
+    return points, quads
 
 
 def test_1024_marschner_lobb_properties(pkg, extractor):
@@ -537,3 +555,68 @@ def test_noise_u8_config5_properties(pkg, extractor):
         poff += n_p
     assert np.array_equal(np.concatenate(cells), whole.cells)
     assert np.array_equal(np.concatenate(pts).view(np.uint32), whole.points.view(np.uint32))
+
+
+def test_2048_noise_u8_config5_full_size(pkg, extractor):
+    """BASELINE.json configs[4] at its full size, 2048^3 uint8 (8.6 GB; one MI355X holds it whole): counts
+    equal the closed form (> 2^27 cells, so ids above the 32-bit segment prefixes are exercised), and the
+    eight 256-slice slabs an 8-GPU node would take -- 8-slice halo, running point/cell offsets as the
+    all-gather gives them -- reproduce the single-shot buffers bit for bit."""
+    import torch
+    n = 2048
+    vol = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
+    for a in range(0, n, 32):
+        vol[a:a + 32] = pkg.volumes.gradient_noise(n, n, n, a, a + 32, xp=torch, device="cuda")
+    torch.cuda.empty_cache()
+    want_pts = want_quads = 0
+    inside = vol >= 128
+    want_pts, want_quads = _closed_form_counts_torch(inside)
+    del inside
+    torch.cuda.empty_cache()
+    prm = pkg.make_params(128, triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+    desc = pkg.make_desc(np.uint8, (n, n, n))
+    extractor.extract_device(vol.data_ptr(), desc, prm)
+    whole = extractor.download()
+    assert (whole.GetNumberOfPoints(), whole.GetNumberOfCells()) == (want_pts, 2 * want_quads)
+    assert 2 * want_quads > (1 << 27)
+    assert int(whole.cells.max()) == want_pts - 1
+    poff = coff = 0
+    for r in range(8):
+        a, b = r * 256, (r + 1) * 256
+        lo, hi = max(a - 8, 0), min(b + 8, n)
+        slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
+        n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (n, n, hi - lo)), prm, slab)
+        extractor.emit(poff, coff)
+        m = extractor.download()
+        assert np.array_equal(m.cells, whole.cells[coff:coff + n_c])
+        assert np.array_equal(m.points.view(np.uint32), whole.points[poff:poff + n_p].view(np.uint32))
+        poff += n_p
+        coff += n_c
+    assert (poff, coff) == (want_pts, 2 * want_quads)
+
+
+def test_hip_path_reproduces_committed_mesh_digests(pkg, extractor, volumes):
+    """The 44 committed digests (11 Data volumes x quads/triangles x projection off/on; oracle output frozen by
+    tests/golden/make_mesh_digests.py): the HIP path gives the same bytes without the oracle in the loop."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mesh_digests.json")))
+    for r in rows:
+        mesh = run_gpu(pkg, extractor, volumes(r["input"]), r["iso"], triangles=r["triangles"], project=r["project"],
+                       threshold=r["threshold"], step=r["step"], relax=r["relax"], max_steps=r["max_steps"])
+        assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (r["points"], r["cells"]), r["input"]
+        assert hashlib.sha256(mesh.points.astype("<f4").tobytes()).hexdigest() == r["points_sha256"], r
+        assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
+
+
+def test_cxx_flat_writer_route_matches_mesh_route(tmp_path):
+    """midas-journal-740_amd/itk/tests/end_to_end.cxx: itk::Mesh fill + itk::VTKPolyDataWriter vs
+    WriteLastMeshAsVTKPolyData (flat device buffers -> file) write the same bytes, quads and triangles."""
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "end_to_end")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(os.path.dirname(exe)), "build/end_to_end"])
+    for tri in ("0", "1"):
+        r = subprocess.run([exe, "72", str(tmp_path / "e2e"), tri], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.stdout, r.stderr[-500:])
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert info["same_bytes"] and info["points"] > 1000 and info["cells"] > 1000

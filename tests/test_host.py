@@ -23,7 +23,7 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == 2
+    assert lib.cuberille_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(pkg):
@@ -146,3 +146,28 @@ def test_dropin_header_compiles_the_unchanged_reference_driver(pkg):
     r = subprocess.run([exe, "Test01", os.path.join(ROOT, "tests", "golden", "data", "blob0.mha"), "/tmp/_blob0.vtk", "200",
                         "8", "6", "0", "0"], capture_output=True, text=True)
     assert r.returncode != 0 and "ExceptionObject caught" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_flat_vtk_writer_bytes(pkg, tmp_path):
+    """cuberille_write_vtk_buffers (host code of the C-ABI library, no GPU needed): the legacy-ASCII POLYDATA
+    layout of itk::VTKPolyDataWriter as used at CuberilleTest01.cxx:180-187 -- 9 significant digits -- for
+    triangles and quads, any thread count, including more items than one formatting chunk."""
+    rng = np.random.default_rng(5)
+    for n_pts, n_cells, k, threads in [(0, 0, 3, 1), (7, 3, 4, 1), (1000, 1999, 3, 3), (300000, 600001, 3, 4)]:
+        pts = (rng.standard_normal((n_pts, 3)) * 10.0 ** rng.integers(-6, 7, (n_pts, 1))).astype(np.float32)
+        if n_pts > 6:
+            pts[0] = (0.0, -0.0, 1.0)
+            pts[1] = (np.nan, np.inf, -np.inf)
+            pts[2] = (1e-5, 123456792.0, 0.1)
+            pts[3] = (-0.5, 40.5, 3.4028235e38)
+        cells = rng.integers(0, max(n_pts, 1), (n_cells, k)).astype(np.uint64)
+        if n_cells:
+            cells[0, 0] = 2 ** 40 + 5
+        path = str(tmp_path / "m.vtk")
+        pkg.Mesh(pts, cells).write_vtk(path, threads)
+        lines = ["# vtk DataFile Version 2.0", "File written by itkVTKPolyDataWriter", "ASCII", "DATASET POLYDATA",
+                 "POINTS %d float" % n_pts]
+        lines += ["%.9g %.9g %.9g" % tuple(float(v) for v in p) for p in pts]
+        lines.append("POLYGONS %d %d" % (n_cells, n_cells * (k + 1)))
+        lines += [" ".join([str(k)] + [str(int(i)) for i in c]) for c in cells]
+        assert open(path, "rb").read() == ("\n".join(lines) + "\n").encode()

@@ -1,6 +1,8 @@
 """CPU tests of the oracle (the checker): pinned against every known-answer vector the reference
 holds for the hot path, cross-checked against an independent numpy closed form, plus the [ITK]
 contract pieces one by one (H7)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,20 @@ def test_faithful_cells_mode_is_identical(oracle, volumes):
     a = oracle.run(vox, 15, faithful_cells=False, gradient_threads=1)
     b = oracle.run(vox, 15, faithful_cells=True, gradient_threads=4)
     assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))
+
+
+def test_oracle_reproduces_committed_mesh_digests(pkg, oracle, volumes):
+    """tests/golden/mesh_digests.json (made by make_mesh_digests.py from this oracle): every bit of every
+    Data mesh -- ids, order, float coordinates -- is frozen, so the checker cannot drift unnoticed."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mesh_digests.json")))
+    assert len(rows) == 44
+    for r in rows:
+        vol = volumes(r["input"])
+        m = oracle.run(vol.voxels, r["iso"], triangles=r["triangles"], project=r["project"], threshold=r["threshold"],
+                       step=r["step"], relax=r["relax"], max_steps=r["max_steps"], spacing=vol.spacing,
+                       origin=vol.origin, direction=vol.direction)
+        assert (m.points.shape[0], m.cells.shape[0]) == (r["points"], r["cells"]), r["input"]
+        assert hashlib.sha256(m.points.astype("<f4").tobytes()).hexdigest() == r["points_sha256"], r["input"]
+        assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
