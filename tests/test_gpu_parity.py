@@ -620,3 +620,57 @@ def test_cxx_flat_writer_route_matches_mesh_route(tmp_path):
         assert r.returncode == 0, (r.stdout, r.stderr[-500:])
         info = json.loads(r.stdout.strip().splitlines()[-1])
         assert info["same_bytes"] and info["points"] > 1000 and info["cells"] > 1000
+
+
+_RCCL_SMOKE = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["CUBERILLE_ROOT"])
+import __graft_entry__ as graft
+pkg = graft.load_package()
+from midas_journal_740_amd.distributed import ShardedExtractor, gather_counts, exchange_halos
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", os.environ["CUBERILLE_PORT"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+try:
+    n = 96
+    vol = pkg.volumes.sphere_sdf(n, xp=torch, device=dev)
+    ex = pkg.Extractor(0)
+    sh = ShardedExtractor(ex, (n, n, n), np.float32, 0, 1)
+    prm = pkg.make_params(0.0, triangles=True, project=True, threshold=0.05, step=0.25)
+    res = sh.extract(vol, prm)
+    counts = gather_counts(int(res.n_points), int(res.n_cells), dev, None)       # all_gather_into_tensor over RCCL
+    assert counts.shape == (1, 2) and counts[0, 0] == res.n_points and counts[0, 1] == res.n_cells
+    reqs, keep = exchange_halos(vol, 0, n, 0, n, 0, 1, None, wait=False)          # no neighbours: nothing posted
+    assert not reqs
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    res2 = sh.extract(vol, prm)                                                   # the library still works after RCCL ran
+    assert (res2.n_points, res2.n_cells) == (res.n_points, res.n_cells) and res.n_points > 1000
+    print("RCCL_SMOKE_OK", int(res.n_points), int(res.n_cells))
+finally:
+    dist.destroy_process_group()
+"""
+
+
+def test_rccl_and_library_share_one_process(tmp_path):
+    """One rank, backend nccl (= RCCL): process-group init, all-gather of the counts on device tensors, all-reduce
+    and barrier next to libcuberille_hip.so in the same process (both must bind the HIP runtime torch ships).  The
+    N>1 exchange itself needs more than one GPU; the gloo rehearsals above cover its logic."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(_RCCL_SMOKE)
+    env = dict(os.environ, CUBERILLE_ROOT=ROOT, CUBERILLE_PORT=str(port))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.stdout[-600:], r.stderr[-1500:])
