@@ -196,6 +196,11 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   g.nx = (int)img->dims[0]; g.ny = (int)img->dims[1]; g.nzb = (int)img->dims[2];
   g.W = (g.nx + 63) / 64;
   g.lastpos = (g.nx - 1) & 63;
+  g.wShift = g.yShift = -1;
+  for (int b = 0; b < 31; b++) {
+    if (g.W == (1 << b)) g.wShift = b;
+    if (g.ny == (1 << b)) g.yShift = b;
+  }
   const bool whole = !slab || (slab->global_nz == 0 && slab->z_begin == 0 && slab->own_z0 == 0 && slab->own_z1 == 0);   // (all-zero slab = whole volume)
   if (whole) {
     g.gnz = g.nzb; g.zglob0 = 0; g.oz0 = 0; g.oz1 = g.nzb;

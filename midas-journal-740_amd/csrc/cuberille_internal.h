@@ -31,6 +31,7 @@ struct Grid {
   int nx, ny, nzb;     // buffer dims (voxels)
   int W;               // 64-voxel words per x-row
   int lastpos;         // (nx-1) & 63
+  int wShift, yShift;  // log2(W), log2(ny) when those are powers of two, else -1 (word index -> k, y, z without dividing)
   int cz0;             // first local slice whose words are counted (own_z0-1 when that exists)
   int oz0, oz1;        // local slices [oz0, oz1) this rank emits
   long long zglob0;    // global z of local slice 0

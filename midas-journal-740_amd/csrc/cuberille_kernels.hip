@@ -221,6 +221,29 @@ __device__ __forceinline__ u64 valid_mask(const Grid &g, int k) {
   return (k == g.W - 1 && g.lastpos != 63) ? ((2ull << g.lastpos) - 1ull) : ~0ull;
 }
 
+// flat word index (counted range) -> word k of row y of local slice z.  Power-of-two rows take shifts;
+// otherwise one 32-bit division pair when the index fits (64-bit division costs more than the whole
+// face test of a word).
+__device__ __forceinline__ void word_coords(const Grid &g, size_t gi, int &k, int &y, int &z) {
+  if (g.wShift >= 0 && g.yShift >= 0) {
+    k = (int)(gi & (size_t)(g.W - 1));
+    const size_t row = gi >> g.wShift;
+    y = (int)(row & (size_t)(g.ny - 1));
+    z = g.cz0 + (int)(row >> g.yShift);
+  } else if (gi <= 0xffffffffull) {
+    const u32 row = (u32)gi / (u32)g.W;
+    k = (int)((u32)gi - row * (u32)g.W);
+    const u32 zz = row / (u32)g.ny;
+    y = (int)(row - zz * (u32)g.ny);
+    z = g.cz0 + (int)zz;
+  } else {
+    const size_t row = gi / g.W;
+    k = (int)(gi % g.W);
+    y = (int)(row % g.ny);
+    z = g.cz0 + (int)(row / g.ny);
+  }
+}
+
 struct WordInfo {
   u64 F[6];   // F[f] bit x: voxel x emits a quad on face f                  (txx:164-173)
   u64 C[8];   // C[i] bit x: voxel x is the first to need its corner i, i.e. the reference
@@ -346,13 +369,13 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     const size_t gi = w0 + i;
     u32 packed = 0;
     if (gi < nwords) {
-      const size_t row = gi / g.W;
-      const int y = (int)(row % g.ny), z = g.cz0 + (int)(row / g.ny);
+      int k, y, z;
+      word_coords(g, gi, k, y, z);
       // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
       // whole runs of such words, so whole waves take the short way)
-      if (bits[((size_t)z * g.ny + y) * g.W + gi % g.W] != 0) {
+      if (bits[((size_t)z * g.ny + y) * g.W + k] != 0) {
         u64 F[6];
-        faces_word(bits, g, y, z, (int)(gi % g.W), F);
+        faces_word(bits, g, y, z, k, F);
         int nQ = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
@@ -367,9 +390,10 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
   for (int j = tid; j < nq; j += 256) {
     const int i = queue[j];
     const size_t gi = w0 + i;
-    const size_t row = gi / g.W;
+    int k, y, z;
+    word_coords(g, gi, k, y, z);
     WordInfo w;
-    classify_word(bits, alias, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), w);
+    classify_word(bits, alias, g, y, z, k, w);
     int nV = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
@@ -580,9 +604,10 @@ __global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo
     const int rEnd = (r0 + EMIT_ROUND < nList) ? r0 + EMIT_ROUND : nList;
     if (r0 + tid < rEnd) {
       const size_t gi = w0 + sb.list[r0 + tid];
-      const size_t row = gi / g.W;
+      int k, y, z;
+      word_coords(g, gi, k, y, z);
       WordInfo w;
-      classify_word(a.bits, a.alias, g, (int)(row % g.ny), g.cz0 + (int)(row / g.ny), (int)(gi % g.W), w);
+      classify_word(a.bits, a.alias, g, y, z, k, w);
 #pragma unroll
       for (int i = 0; i < 8; i++) masks[i][tid] = w.C[i];
     }
@@ -612,10 +637,9 @@ __global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo
       }
       const int e = kCornerEnc[select_bit8(cm, (int)r - before)];
       const size_t gi = w0 + wi;
-      const size_t row = gi / g.W;
-      const int cx = (int)(gi % g.W) * 64 + lo + (e & 1);
-      const int cy = (int)(row % g.ny) + ((e >> 1) & 1);
-      const int cz = g.cz0 + (int)(row / g.ny) + (e >> 2);
+      int k, y, z;
+      word_coords(g, gi, k, y, z);
+      const int cx = k * 64 + lo + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
       const u64 v = base + o;                    // vertex index in the counted range
       float p[3];
       corner_point(geo, cx, cy, g.zglob0 + cz, p);
@@ -711,10 +735,8 @@ __global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Ge
   u32 r = 0;
   const size_t gi = locate_word_wave<0>(a.segBaseV, a.prefix, a.headV, nseg, nwords, v, v < nV, r);
   if (v >= nV) return;
-  const size_t row = gi / g.W;
-  const int k = (int)(gi % g.W);
-  const int y = (int)(row % g.ny);
-  const int z = g.cz0 + (int)(row / g.ny);
+  int k, y, z;
+  word_coords(g, gi, k, y, z);
   WordInfo w;
   classify_word(a.bits, a.alias, g, y, z, k, w);
   int lo = 0, hi = 64;                           // largest bit position with (#created before it) <= r
@@ -749,11 +771,11 @@ __global__ __launch_bounds__(256) void k_emit_points_queue(EmitArgs a, Grid g, G
                                                            u32 nVertexWords) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nVertexWords) return;
-  const size_t gi = vqueue[t];
-  const size_t row = gi / g.W;
-  const int k = (int)(gi % g.W);
-  const int y = (int)(row % g.ny);
-  const int z = g.cz0 + (int)(row / g.ny);
+  const u32 gi = vqueue[t];
+  const u32 row = gi / (u32)g.W;                 // (measured: the shift form of word_coords is slower in this kernel)
+  const int k = (int)(gi - row * (u32)g.W);
+  const u32 zz = row / (u32)g.ny;
+  const int y = (int)(row - zz * (u32)g.ny), z = g.cz0 + (int)zz;
   WordInfo w;
   classify_word(a.bits, a.alias, g, y, z, k, w);
   u64 v = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);       // id of this word's first vertex
@@ -856,10 +878,8 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
   if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a.segBaseQ, a.prefix, a.headQ, nseg, nwords, q + Q0, q < nQ, r);
   else gi = (q < nQ) ? locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r) : 0;
   if (q >= nQ) return;
-  const size_t row = gi / g.W;
-  const int k = (int)(gi % g.W);
-  const int y = (int)(row % g.ny);
-  const int z = g.cz0 + (int)(row / g.ny);
+  int k, y, z;
+  word_coords(g, gi, k, y, z);
   u64 F[6];
   faces_word(a.bits, g, y, z, k, F);
   int lo = 0, hi = 64;
