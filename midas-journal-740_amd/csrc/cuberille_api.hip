@@ -44,7 +44,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ, vqueue;
+  DevBuf voxOwn, bits, flatBits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ, vqueue;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   // state of the last count
@@ -260,6 +260,11 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   const size_t tempBytes = scan_temp_bytes(nseg);
   HIP_TRY(c, c->scanTemp.reserve(tempBytes));
   Workspace w{};
+  w.flatBits = nullptr;
+  if (g.nx % 64 != 0) {   // ragged rows: thresholded as one flat stream first, then cut into rows
+    if (c->flatBits.reserve((nwordsAll + 32) * sizeof(u64)) == hipSuccess) w.flatBits = (u64 *)c->flatBits.p;
+    else (void)hipGetLastError();
+  }
   w.vqueue = nullptr;
   if (nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_VQUEUE") && c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess)
     w.vqueue = (u32 *)c->vqueue.p;

@@ -51,6 +51,7 @@ enum { ERRF_ALIAS_UNKNOWN = 1 };
 struct Workspace {     // device pointers valid for one count/emit pair
   const void *vox;
   u64 *bits;
+  u64 *flatBits;       // scratch for rows that are not whole words: inside bits in flat voxel order (or null)
   u32 *sliceOcc;
   int *alias;          // per local slice: source slice of the empty-slice aliasing or -1
   u32 *prefix;         // per counted word: exclusive in-segment prefix, V | Q<<16

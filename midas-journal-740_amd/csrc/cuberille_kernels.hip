@@ -134,6 +134,50 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
   }
 }
 
+// Ragged rows (nx % 64 != 0), the fast way: k_classify_flat thresholds the slices as ONE flat stream of 16-byte
+// vectors starting at the 16-byte boundary at or below the first voxel (`skew` voxels earlier); this kernel
+// finishes the last, partial 1 KiB chunk ...
+template <class T>
+__global__ __launch_bounds__(64) void k_classify_tail(const T *__restrict__ abase, u64 *__restrict__ flat, u64 firstVec,
+                                                      u64 nvec, double isoD) {
+  constexpr int VPL = 16 / sizeof(T);
+  constexpr int LPW = 64 / VPL;
+  const T iso = (T)isoD;
+  const int lane = threadIdx.x & 63;
+  const u64 v = firstVec + lane;
+  u32 m = 0;
+  if (v < nvec) {
+    Vec16<T> r;
+    r.raw = *reinterpret_cast<const uint4 *>(abase + v * VPL);
+    m = inside_bits<T>(r, iso);
+  }
+  const int sub = lane % LPW;
+  u64 part = (u64)m << (sub * VPL);
+#pragma unroll
+  for (int s = 1; s < LPW; s <<= 1) part |= __shfl_xor(part, s, 64);
+  if (sub == 0) flat[(firstVec * VPL) / 64 + lane / LPW] = part;
+}
+
+// ... and this one cuts the flat bit stream into rows: word k of row r is 64 bits of the stream from bit
+// skew + r*nx + 64k on (two flat words, funnel-shifted), masked to the voxels the row really has.
+__global__ __launch_bounds__(256) void k_repack_rows(const u64 *__restrict__ flat, u64 *__restrict__ bits, int nx, int W,
+                                                     u64 nrows, u64 skew) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 total = nrows * (u64)W;
+  if (t >= total) return;
+  u64 row;
+  int k;
+  if (total <= 0xffffffffull) { const u32 r = (u32)t / (u32)W; row = r; k = (int)((u32)t - r * (u32)W); }
+  else { row = t / (u64)W; k = (int)(t % (u64)W); }
+  const u64 sbit = skew + row * (u64)nx + (u64)k * 64;
+  const int sh = (int)(sbit & 63);
+  const u64 lo = flat[sbit >> 6], hi = flat[(sbit >> 6) + 1];
+  u64 word = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+  const int n = nx - k * 64;
+  if (n < 64) word &= lowmask(n);
+  bits[t] = word;
+}
+
 // Generic path (any nx): one wave per (row, word); lane l tests voxel x = 64k + l; the
 // wave ballot IS the packed word.
 template <class T>
@@ -1289,6 +1333,24 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       if (nchunks * VPL < nwordsAll)
         hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, nchunks * VPL, nrows,
                            (u64)g.ny, iso, w.sliceOcc);
+    } else if (wAll.flatBits && ((uintptr_t)vox % sizeof(T)) == 0 && !getenv("CUBERILLE_NO_STREAM_CLASSIFY")) {
+      // ragged rows: flat stream of aligned 16-byte vectors (the first and last vector may reach up to 15 bytes
+      // outside the range -- same 16-byte granule as valid voxels, so the loads cannot fault, and those bits
+      // are never used), then cut into rows.  Each z-range uses its own part of the scratch.
+      constexpr int VPL = 16 / sizeof(T);
+      const uintptr_t addr = (uintptr_t)vox, aaddr = addr & ~(uintptr_t)15;
+      const u64 skew = (u64)(addr - aaddr) / sizeof(T);
+      const T *abase = (const T *)aaddr;
+      u64 *flat = wAll.flatBits + (size_t)z0 * g.ny * g.W;
+      const u64 nvec = (skew + nrows * (u64)g.nx + VPL - 1) / VPL;
+      const u64 nchunks = nvec / 64;
+      if (nchunks) {
+        const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, 2048);
+        hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, abase, flat, nchunks, iso,
+                           (u32 *)nullptr, -1);
+      }
+      if (nvec % 64) hipLaunchKernelGGL((k_classify_tail<T>), dim3(1), dim3(64), 0, s, abase, flat, nchunks * 64, nvec, iso);
+      hipLaunchKernelGGL(k_repack_rows, dim3(grid_for(nrows * g.W, 256, 0)), dim3(256), 0, s, flat, w.bits, g.nx, g.W, nrows, skew);
     } else {
       const u64 total = nrows * g.W;
       const unsigned blocks = grid_for(total * 64, 256, 8192);

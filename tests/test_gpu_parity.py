@@ -674,3 +674,32 @@ def test_rccl_and_library_share_one_process(tmp_path):
     env = dict(os.environ, CUBERILLE_ROOT=ROOT, CUBERILLE_PORT=str(port))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.stdout[-600:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32, np.float64])
+def test_ragged_rows_at_every_pointer_alignment(pkg, oracle, extractor, dtype):
+    """Rows that are not whole 64-voxel words go through the flat-stream threshold + row repack; the stream
+    starts at the 16-byte boundary below the first voxel, so every misalignment of the device pointer (and
+    the old one-voxel-per-lane kernel, CUBERILLE_NO_STREAM_CLASSIFY) must give the oracle's mesh."""
+    import torch
+    rng = np.random.default_rng(11)
+    item = np.dtype(dtype).itemsize
+    for shape in [(3, 5, 71), (2, 3, 1), (4, 2, 129), (1, 1, 300), (5, 7, 63)]:
+        vol = (rng.random(shape) * 200).astype(dtype)
+        want = oracle.run(vol, 100, triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=20)
+        nz, ny, nx = shape
+        desc = pkg.make_desc(dtype, (nx, ny, nz))
+        prm = pkg.make_params(100, triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=20)
+        raw = torch.zeros(vol.nbytes + 64, dtype=torch.uint8, device="cuda")
+        for skew in range(0, 16, item):
+            raw.zero_()
+            raw[skew:skew + vol.nbytes] = torch.from_numpy(vol.view(np.uint8).reshape(-1)).cuda()
+            torch.cuda.synchronize()
+            extractor.extract_device(raw.data_ptr() + skew, desc, prm)
+            assert_same_mesh(extractor.download(), want)
+    os.environ["CUBERILLE_NO_STREAM_CLASSIFY"] = "1"
+    try:
+        extractor.extract_device(raw.data_ptr() + skew, desc, prm)
+        assert_same_mesh(extractor.download(), want)
+    finally:
+        del os.environ["CUBERILLE_NO_STREAM_CLASSIFY"]
