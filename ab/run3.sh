@@ -1,0 +1,11 @@
+for i in 1 2; do
+for lib in ab/lib_old.so midas-journal-740_amd/csrc/libcuberille_hip.so; do
+  CUBERILLE_LIB=$PWD/$lib python bench.py --cpu-sample 0 --steps 20 --warmup 3 2>/dev/null | python -c "
+import sys,json; j=json.loads(sys.stdin.readline()); s=j['stages_ms']; print('$lib', j['value'], ' '.join('%s %.3f'%(k[3:],v) for k,v in s.items()))"
+done; done
+for lib in ab/lib_old.so midas-journal-740_amd/csrc/libcuberille_hip.so; do
+  CUBERILLE_LIB=$PWD/$lib python bench.py --cpu-sample 0 --workload noise --size 1024 2>/dev/null | python -c "
+import sys,json; j=json.loads(sys.stdin.readline()); s=j['stages_ms']; print('$lib noise1024', j['value'], ' '.join('%s %.3f'%(k[3:],v) for k,v in s.items()))"
+  CUBERILLE_LIB=$PWD/$lib python bench.py --cpu-sample 0 --workload sphere --size 512 2>/dev/null | python -c "
+import sys,json; j=json.loads(sys.stdin.readline()); s=j['stages_ms']; print('$lib sphere512', j['value'], ' '.join('%s %.3f'%(k[3:],v) for k,v in s.items()))"
+done

@@ -1054,7 +1054,12 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
 // Gather of the cell around a vertex: the eight lattice-site pixel values and gradients.  When the
 // cell lies inside the image (lo+1 == hi on every axis) the 56 taps are 32 distinct pixels: all 32
 // loads are issued back to back (one memory latency per gather) from 12 row segments.
-template <class T>
+// LITERAL = false shortens the gradient of an interior cell to (-c)*f(-1) + c*f(+1) per axis: with finite taps
+// that is the reference's 0 + (-c)*f(-1) + 0*f(0) + c*f(+1) (and, for the identity direction, its 0 + 1*v + 0*w + 0*u)
+// up to the SIGN OF A ZERO result, and a zero gradient component only ever enters the walk as a term added to a
+// sum that starts at +0 -- so the walk cannot tell.  Non-finite taps always give a non-finite component here too;
+// the caller tests for that and gathers again with LITERAL = true.
+template <class T, bool LITERAL>
 __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo, bool dirIdentity, const Cell8 &c,
                                             float G[8][3], double Vd[8]) {
   if (c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2]) {
@@ -1086,7 +1091,25 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
       const float fm[3] = {(float)V[cz][b][a - 1], (float)V[cz][b - 1][a], (float)V[cz - 1][b][a]};
       const float fp[3] = {(float)V[cz][b][a + 1], (float)V[cz][b + 1][a], (float)V[cz + 1][b][a]};
       Vd[counter] = (double)pix;
-      gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
+      if (LITERAL) {
+        gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
+      } else {
+        float local[3];
+#pragma unroll
+        for (int a_ = 0; a_ < 3; a_++) local[a_] = (-geo.gcoef[a_]) * fm[a_] + geo.gcoef[a_] * fp[a_];
+        if (dirIdentity) {                       // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 3; r++) G[counter][r] = local[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) sum = (float)((double)sum + geo.dir[r * 3 + cc] * (double)local[cc]);
+            G[counter][r] = sum;
+          }
+        }
+      }
     }
   } else {
     // vertex on or beyond the image border: clamped neighbours, generic taps
@@ -1179,17 +1202,20 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       make_cell(geo, unitP2I, n, p, c);
       if (c.lo[0] != kl[0] || c.lo[1] != kl[1] || c.lo[2] != kl[2] || c.hi[0] != kh[0] || c.hi[1] != kh[1] ||
           c.hi[2] != kh[2]) {
-        gather_cell(s, geo, dirIdentity != 0, c, G, Vd);
+        gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
         for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
-        u32 emax = 0;                             // largest exponent field among the 32 cached floats
+        // all 32 cached numbers finite?  x*0 accumulates to 0 for finite x, to NaN for an infinity or a NaN
+        float tf = 0.0f;
+        double td = 0.0;
 #pragma unroll
         for (int counter = 0; counter < 8; counter++) {
-          emax = max(emax, __float_as_uint((float)Vd[counter]) & 0x7f800000u);
+          td = __builtin_fma(Vd[counter], 0.0, td);
 #pragma unroll
-          for (int k = 0; k < 3; k++) emax = max(emax, __float_as_uint(G[counter][k]) & 0x7f800000u);
+          for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
         }
-        cellFinite = emax != 0x7f800000u;
+        cellFinite = (tf == 0.0f) && (td == 0.0);
+        if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);   // rare: the reference's formula to the letter
       }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
       // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite

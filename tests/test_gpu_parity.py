@@ -703,3 +703,32 @@ def test_ragged_rows_at_every_pointer_alignment(pkg, oracle, extractor, dtype):
         assert_same_mesh(extractor.download(), want)
     finally:
         del os.environ["CUBERILLE_NO_STREAM_CLASSIFY"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_nonfinite_and_signed_zero_voxels_walk_like_the_oracle(pkg, oracle, extractor, dtype):
+    """The projection shortens the gradient of a cell with finite taps to (-c)f(-1) + c f(+1) (equal to the
+    reference's four-term sum up to the sign of a zero) and replays the reference's formula to the letter when
+    any cached number is not finite.  Volumes built to sit on both sides of that switch: many exact +0 / -0
+    voxels (zero and negative-zero gradient components), infinities and NaNs next to the surface, and
+    anisotropic spacing with a rotated direction matrix (the general direction transform)."""
+    rng = np.random.default_rng(21)
+    th = 0.3
+    rot = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    for trial in range(6):
+        shape = (9, 10, 70) if trial % 2 else (12, 9, 33)
+        vol = rng.standard_normal(shape)
+        vol[rng.random(shape) < 0.35] = 0.0
+        vol[rng.random(shape) < 0.15] = -0.0
+        if trial >= 2:
+            bad = rng.random(shape)
+            vol[bad < 0.01] = np.inf
+            vol[(bad >= 0.01) & (bad < 0.02)] = -np.inf
+            vol[(bad >= 0.02) & (bad < 0.03)] = np.nan
+        vol = vol.astype(dtype)
+        geo = {} if trial % 3 else dict(spacing=(0.7, 1.3, 2.1), origin=(-3.0, 4.0, 0.5), direction=rot)
+        for iso in (0.0, 0.25):
+            kw = dict(triangles=1, project=1, threshold=0.01, step=0.25, relax=0.95, max_steps=30)
+            want = oracle.run(vol, iso, **kw, **geo)
+            got = run_gpu(pkg, extractor, pkg.Volume(vol, **geo), iso, **kw)
+            assert_same_mesh(got, want)
