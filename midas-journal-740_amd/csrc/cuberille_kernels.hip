@@ -1051,6 +1051,39 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
   gradient_from_taps(geo, dirIdentity, fm, f0, fp, out);
 }
 
+// the eight lattice-site values and gradients of a cell from its gathered 4x4x4 neighbourhood (32 entries used)
+template <class T, bool LITERAL>
+__device__ __forceinline__ void cell_gradients(const Geo &geo, bool dirIdentity, const T (&V)[4][4][4], float G[8][3],
+                                               double Vd[8]) {
+#pragma unroll
+  for (int counter = 0; counter < 8; counter++) {
+    const int a = (counter & 1) + 1, b = ((counter >> 1) & 1) + 1, cz = (counter >> 2) + 1;
+    const T pix = V[cz][b][a];
+    const float fm[3] = {(float)V[cz][b][a - 1], (float)V[cz][b - 1][a], (float)V[cz - 1][b][a]};
+    const float fp[3] = {(float)V[cz][b][a + 1], (float)V[cz][b + 1][a], (float)V[cz + 1][b][a]};
+    Vd[counter] = (double)pix;
+    if (LITERAL) {
+      gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
+    } else {
+      float local[3];
+#pragma unroll
+      for (int a_ = 0; a_ < 3; a_++) local[a_] = (-geo.gcoef[a_]) * fm[a_] + geo.gcoef[a_] * fp[a_];
+      if (dirIdentity) {                         // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 3; r++) G[counter][r] = local[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++) sum = (float)((double)sum + geo.dir[r * 3 + cc] * (double)local[cc]);
+          G[counter][r] = sum;
+        }
+      }
+    }
+  }
+}
+
 // Gather of the cell around a vertex: the eight lattice-site pixel values and gradients.  When the
 // cell lies inside the image (lo+1 == hi on every axis) the 56 taps are 32 distinct pixels: all 32
 // loads are issued back to back (one memory latency per gather) from 12 row segments.
@@ -1062,7 +1095,31 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
 template <class T, bool LITERAL>
 __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo, bool dirIdentity, const Cell8 &c,
                                             float G[8][3], double Vd[8]) {
-  if (c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2]) {
+  const bool unit = c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2];
+  const int zl = c.lo[2] - s.zglob0;              // buffer slice of the cell's lower z
+  if (unit && c.lo[0] >= 1 && c.lo[0] + 2 < s.nx && c.lo[1] >= 1 && c.lo[1] + 2 < s.ny && zl >= 1 && zl + 2 < s.nzb) {
+    // the cell and its ring of neighbours lie inside the buffer: nothing is clamped, so the 12 row segments are
+    // the cell's own address plus wave-uniform strides, and the x neighbours are immediate offsets
+    const T *base = s.vox + ((size_t)zl * s.ny + c.lo[1]) * s.nx + c.lo[0];
+    const ptrdiff_t rowS = (ptrdiff_t)s.nx, sliceS = (ptrdiff_t)s.ny * s.nx;
+    T V[4][4][4];
+#pragma unroll
+    for (int zi = 0; zi < 4; zi++)
+#pragma unroll
+      for (int yi = 0; yi < 4; yi++) {
+        const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2);
+        if (!zin && !yin) continue;
+        const T *row = base + (zi - 1) * sliceS + (yi - 1) * rowS;
+        if (zin && yin) {
+#pragma unroll
+          for (int xi = 0; xi < 4; xi++) V[zi][yi][xi] = row[xi - 1];
+        } else {
+          V[zi][yi][1] = row[0];
+          V[zi][yi][2] = row[1];
+        }
+      }
+    cell_gradients<T, LITERAL>(geo, dirIdentity, V, G, Vd);
+  } else if (unit) {
     int xs[4], ys[4], zs[4];
     xs[0] = c.lo[0] > 0 ? c.lo[0] - 1 : 0;  xs[1] = c.lo[0];  xs[2] = c.hi[0];  xs[3] = c.hi[0] < s.nx - 1 ? c.hi[0] + 1 : s.nx - 1;
     ys[0] = c.lo[1] > 0 ? c.lo[1] - 1 : 0;  ys[1] = c.lo[1];  ys[2] = c.hi[1];  ys[3] = c.hi[1] < s.ny - 1 ? c.hi[1] + 1 : s.ny - 1;
@@ -1084,33 +1141,7 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
           V[zi][yi][2] = row[xs[2]];
         }
       }
-#pragma unroll
-    for (int counter = 0; counter < 8; counter++) {
-      const int a = (counter & 1) + 1, b = ((counter >> 1) & 1) + 1, cz = (counter >> 2) + 1;
-      const T pix = V[cz][b][a];
-      const float fm[3] = {(float)V[cz][b][a - 1], (float)V[cz][b - 1][a], (float)V[cz - 1][b][a]};
-      const float fp[3] = {(float)V[cz][b][a + 1], (float)V[cz][b + 1][a], (float)V[cz + 1][b][a]};
-      Vd[counter] = (double)pix;
-      if (LITERAL) {
-        gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
-      } else {
-        float local[3];
-#pragma unroll
-        for (int a_ = 0; a_ < 3; a_++) local[a_] = (-geo.gcoef[a_]) * fm[a_] + geo.gcoef[a_] * fp[a_];
-        if (dirIdentity) {                       // wave-uniform
-#pragma unroll
-          for (int r = 0; r < 3; r++) G[counter][r] = local[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) sum = (float)((double)sum + geo.dir[r * 3 + cc] * (double)local[cc]);
-            G[counter][r] = sum;
-          }
-        }
-      }
-    }
+    cell_gradients<T, LITERAL>(geo, dirIdentity, V, G, Vd);
   } else {
     // vertex on or beyond the image border: clamped neighbours, generic taps
 #pragma unroll
