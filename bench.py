@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--workload", default="marschner_lobb", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the cube the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-project", action="store_true")
+    ap.add_argument("--gather-mesh", action="store_true",
+                    help="N>1: after the timed region also concatenate the rank parts on rank 0 and report its time")
     ap.add_argument("--thr", type=float, default=None, help="override the projection threshold (experiments)")
     args = ap.parse_args()
 
@@ -195,6 +197,17 @@ def main():
     else:
         n_points, n_cells = int(res.n_points), int(res.n_cells)
 
+    gather_ms = None
+    if world > 1 and args.gather_mesh:
+        # outside the timed region: mesh concatenation in rank order on rank 0 (device to device over RCCL)
+        barrier()
+        t0 = time.perf_counter()
+        whole = sh.gather_mesh(dst=0)
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        if rank == 0:
+            assert (whole.GetNumberOfPoints(), whole.GetNumberOfCells()) == (n_points, n_cells)
+        del whole
+
     if rank == 0:
         voxels = float(n) * n * gnz
         stages = {k: acc[k] / args.steps for k in stage_keys}
@@ -232,6 +245,8 @@ def main():
         # largest kernel is the projection, which is f64-VALU-bound (neither an HBM nor an MFMA roofline)
         out["roofline"]["note"] = ("largest kernel by time is k_project (%.0f %% of device time): f64 VALU-bound gradient walk; "
                                    "the HBM roofline applies to the classify sweep" % (100.0 * stages["ms_project"] / stages["ms_total"]))
+        if gather_ms is not None:
+            out["gather_mesh_ms"] = round(gather_ms, 1)
         if world == 1:
             # outside the timed region, reported separately: copying the mesh to the host
             t0 = time.perf_counter()

@@ -88,6 +88,28 @@ def gather_counts(n_points, n_cells, device, group=None):
     return out.cpu().numpy().reshape(world, 2)
 
 
+class _DeviceArray:
+    """Zero-copy view of library-owned device memory for torch (CUDA array interface, version 2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def mesh_tensors(extractor, device):
+    """The last mesh part of `extractor` as torch tensors WITHOUT copying: points float32 [n,3], cells int64 [m,k]
+    (the uint64 ids reinterpreted; they are < 2^63).  Valid until the next call on the extractor."""
+    import torch
+    res = extractor.result
+    n, m, k = int(res.n_points), int(res.n_cells), int(res.verts_per_cell)
+    pp, cp = extractor.device_pointers()
+    pts = torch.as_tensor(_DeviceArray(pp, (n, 3), "<f4"), device=device) if n else \
+        torch.empty((0, 3), dtype=torch.float32, device=device)
+    cells = torch.as_tensor(_DeviceArray(cp, (m, k), "<i8"), device=device) if m else \
+        torch.empty((0, k), dtype=torch.int64, device=device)
+    return pts, cells
+
+
 def id_offsets(counts, rank):
     """Exclusive prefix over ranks of the gathered counts -> (point_id_offset, cell_id_offset)."""
     c = np.asarray(counts, dtype=np.int64)
@@ -175,3 +197,58 @@ class ShardedExtractor:
             self.counts = np.array([[n_p, n_c]], dtype=np.int64)
             poff, coff = 0, 0
         return self.ex.emit(poff, coff)
+
+    def gather_mesh(self, dst=0, on_device=None):
+        """Concatenate the rank parts in rank order on rank `dst` (collective 3): the
+        gathered counts give every part's place, so `dst` posts one receive per rank straight into its slice of
+        the whole buffers and every other rank one send of its part -- device to device over RCCL (xGMI), or
+        host buffers over gloo.  Returns a Mesh of numpy arrays on `dst` (cells hold global ids already), None
+        elsewhere.  on_device: transport device tensors (default: exactly when the backend is nccl)."""
+        import torch
+        import torch.distributed as dist
+        from .cuberille import Mesh
+        if self.counts is None:
+            raise RuntimeError("gather_mesh before extract")
+        counts = np.asarray(self.counts, dtype=np.int64)
+        vpc = int(self.ex.result.verts_per_cell)
+        if self.world == 1:
+            return self.ex.download()
+        if on_device is None:
+            on_device = dist.get_backend(self.group) == "nccl"
+        if on_device:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            torch.cuda.synchronize()
+            pts, cells = mesh_tensors(self.ex, dev)
+        else:
+            dev = torch.device("cpu")
+            part = self.ex.download()
+            pts = torch.from_numpy(part.points)
+            cells = torch.from_numpy(part.cells.view(np.int64))
+        poff = np.concatenate([[0], np.cumsum(counts[:, 0])])
+        coff = np.concatenate([[0], np.cumsum(counts[:, 1])])
+        ops = []
+        if self.rank == dst:
+            all_pts = torch.empty((int(poff[-1]), 3), dtype=torch.float32, device=dev)
+            all_cells = torch.empty((int(coff[-1]), vpc), dtype=torch.int64, device=dev)
+            for r in range(self.world):
+                ps, cs = all_pts[int(poff[r]):int(poff[r + 1])], all_cells[int(coff[r]):int(coff[r + 1])]
+                if r == dst:
+                    ps.copy_(pts)
+                    cs.copy_(cells)
+                else:
+                    if ps.numel():
+                        ops.append(dist.P2POp(dist.irecv, ps, r, self.group))
+                    if cs.numel():
+                        ops.append(dist.P2POp(dist.irecv, cs, r, self.group))
+        else:
+            if pts.numel():
+                ops.append(dist.P2POp(dist.isend, pts.contiguous(), dst, self.group))
+            if cells.numel():
+                ops.append(dist.P2POp(dist.isend, cells.contiguous(), dst, self.group))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        if on_device:
+            torch.cuda.synchronize()
+        if self.rank != dst:
+            return None
+        return Mesh(all_pts.cpu().numpy(), all_cells.cpu().numpy().view(np.uint64))

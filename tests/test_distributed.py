@@ -43,6 +43,21 @@ def _worker(rank, world, port, nz, out_dir):
         assert counts.tolist() == [[100 * (r + 1), 7 * (r + 1)] for r in range(world)]
         poff, coff = D.id_offsets(counts, rank)
         assert poff == sum(100 * (r + 1) for r in range(rank)) and coff == sum(7 * (r + 1) for r in range(rank))
+        # mesh concatenation in rank order on rank 0 (host buffers over gloo), with a stand-in for the GPU extractor
+        import types
+        from midas_journal_740_amd.cuberille import Mesh
+        n_p, n_c = 10 * (rank + 1), 4 * (rank + 1) if rank != 1 else 0        # one rank without cells
+        part = Mesh(np.full((n_p, 3), float(rank), dtype=np.float32) + np.arange(n_p, dtype=np.float32)[:, None],
+                    (np.arange(n_c * 3, dtype=np.uint64).reshape(n_c, 3) + np.uint64(1000 * rank)))
+        fake = types.SimpleNamespace(result=types.SimpleNamespace(n_points=n_p, n_cells=n_c, verts_per_cell=3),
+                                     download=lambda: part)
+        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world)
+        sh.counts = D.gather_counts(n_p, n_c, torch.device("cpu"))
+        whole = sh.gather_mesh(dst=0)
+        assert (whole is None) == (rank != 0)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "gp.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc.npy"), whole.cells)
         np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([z0, z1, lo, hi]))
     finally:
         dist.destroy_process_group()
@@ -56,6 +71,13 @@ def test_halo_exchange_and_offsets_gloo(tmp_path, world, nz):
     assert spans[0][0] == 0 and spans[-1][1] == nz
     for a, b in zip(spans[:-1], spans[1:]):
         assert a[1] == b[0]
+    want_p = np.concatenate([np.full((10 * (r + 1), 3), float(r), dtype=np.float32)
+                             + np.arange(10 * (r + 1), dtype=np.float32)[:, None] for r in range(world)])
+    want_c = np.concatenate([np.arange((4 * (r + 1) if r != 1 else 0) * 3, dtype=np.uint64).reshape(-1, 3) + np.uint64(1000 * r)
+                             for r in range(world)])
+    assert np.array_equal(np.load(str(tmp_path / "gp.npy")), want_p)
+    got_c = np.load(str(tmp_path / "gc.npy"))
+    assert got_c.dtype == np.uint64 and np.array_equal(got_c, want_c)
 
 
 def test_slab_plan():

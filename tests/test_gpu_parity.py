@@ -303,6 +303,13 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
         m = ex.download()
         np.save(os.path.join(out_dir, "p%d.npy" % rank), m.points)
         np.save(os.path.join(out_dir, "c%d.npy" % rank), m.cells)
+        # mesh concatenation on the last rank: host buffers over gloo, or (event_path) device tensors viewed
+        # straight out of the library's buffers, the way RCCL runs move them
+        whole = sh.gather_mesh(dst=world - 1, on_device=bool(event_path))
+        assert (whole is None) == (rank != world - 1)
+        if whole is not None:
+            np.save(os.path.join(out_dir, "gp.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc.npy"), whole.cells)
         ex.close()
     finally:
         dist.destroy_process_group()
@@ -331,6 +338,8 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
         pass
     m = M()
     m.points, m.cells = pts, cells
+    assert_same_mesh(m, ref)
+    m.points, m.cells = np.load(str(tmp_path / "gp.npy")), np.load(str(tmp_path / "gc.npy"))   # gather_mesh on rank world-1
     assert_same_mesh(m, ref)
 
 
