@@ -1295,8 +1295,29 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 #pragma unroll
         for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
         const double norm = sqrt(sq);
+        if (norm > 0.0 && norm < __builtin_inf()) {
+          // Three quotients by one denominator.  The compiler expands an f64 `/` into div_scale, rcp, two Newton
+          // steps on the reciprocal, q0 = n*y, r = fma(-d, q0, n), q = fma(r, y, q0), div_fixup.  Here every
+          // numerator is a float (zero, or 2^-149 <= |n| < 2^128) and d = sqrt of their squares is finite and
+          // positive, so div_scale never scales and div_fixup only restores the sign of a zero quotient: the
+          // same instructions with the reciprocal refined ONCE give the same bits (IEEE-rounded quotients).
+          double y = __builtin_amdgcn_rcp(norm);
+          double e = __builtin_fma(-norm, y, 1.0);
+          y = __builtin_fma(y, e, y);
+          e = __builtin_fma(-norm, y, 1.0);
+          y = __builtin_fma(y, e, y);
 #pragma unroll
-        for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+          for (int k = 0; k < 3; k++) {
+            const double x = (double)normal[k];
+            const double q0 = x * y;
+            const double r = __builtin_fma(-norm, q0, x);
+            const double q = __builtin_fma(r, y, q0);
+            normal[k] = (float)__builtin_copysign(q, x);     // -0 / d is -0 (the fma chain alone would give +0)
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+        }
         const double sign = (value < iso) ? +1.0 : -1.0;                      // txx:463
 #pragma unroll
         for (int k = 0; k < 3; k++)                                           // txx:464-467 (I9)
