@@ -1294,8 +1294,19 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         double sq = 0.0;                                                      // I8
 #pragma unroll
         for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
-        const double norm = sqrt(sq);
-        if (norm > 0.0 && norm < __builtin_inf()) {
+        if (sq > 0.0 && sq < __builtin_inf()) {
+          // sq is a sum of squares of floats, so it lies in [2^-298, 2^258): the compiler's f64 sqrt (rsq + the
+          // refinement below, wrapped in a rescaling for arguments under 2^-767 and a pass-through for 0 and
+          // infinity) reduces to exactly these instructions.
+          const double y0 = __builtin_amdgcn_rsq(sq);
+          double gs = sq * y0, hs = y0 * 0.5;
+          const double rs = __builtin_fma(-hs, gs, 0.5);
+          gs = __builtin_fma(gs, rs, gs);
+          hs = __builtin_fma(hs, rs, hs);
+          double ds = __builtin_fma(-gs, gs, sq);
+          gs = __builtin_fma(ds, hs, gs);
+          ds = __builtin_fma(-gs, gs, sq);
+          const double norm = __builtin_fma(ds, hs, gs);
           // Three quotients by one denominator.  The compiler expands an f64 `/` into div_scale, rcp, two Newton
           // steps on the reciprocal, q0 = n*y, r = fma(-d, q0, n), q = fma(r, y, q0), div_fixup.  Here every
           // numerator is a float (zero, or 2^-149 <= |n| < 2^128) and d = sqrt of their squares is finite and
@@ -1315,6 +1326,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
             normal[k] = (float)__builtin_copysign(q, x);     // -0 / d is -0 (the fma chain alone would give +0)
           }
         } else {
+          const double norm = sqrt(sq);
 #pragma unroll
           for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
         }
