@@ -1226,7 +1226,6 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
     }
     if (!__ballot(active)) break;
     if (active) {
-      if (idx >= nGhost) myIters++;
       bool done = false;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
@@ -1263,9 +1262,13 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       }
       bool literal = !cellFinite || forceLiteral;
       {
+        // the weights are >= 0, so the rounded partial sums never decrease: if the sum of the first seven is
+        // below 1 none of them is 1 (a sum that is not below 1 -- or NaN -- takes the literal loop, which is
+        // always right)
         double t = 0.0;
 #pragma unroll
-        for (int counter = 0; counter < 7; counter++) { t += o[counter]; literal |= (t == 1.0); }
+        for (int counter = 0; counter < 7; counter++) t += o[counter];
+        literal |= !(t < 1.0);
       }
       double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
       if (!literal) {
@@ -1288,6 +1291,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         }
       }
       done = fabs(value - iso) < prm.thr;                                     // txx:456
+      const unsigned passes = numberOfSteps + 1;       // loop passes of this vertex if it ends in this one
       if (!done) {
         // (the reference normalises before the test, txx:452; the normal is only used when stepping)
         float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
@@ -1339,6 +1343,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       }
       if (done) {
         points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
+        if (idx >= nGhost) myIters += passes;          // the iteration statistic counts owned vertices only
         active = false;
       }
     }

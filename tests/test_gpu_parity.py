@@ -43,6 +43,8 @@ def test_data_volumes_match_oracle(pkg, oracle, extractor, volumes, name, iso, m
             mesh = run_gpu(pkg, extractor, vol, iso, **kw)
             ref = oracle.run(vol.voxels, iso, **kw)
             assert_same_mesh(mesh, ref)
+            # same number of passes through the walk loop (txx:449-470) as the oracle, vertex for vertex in total
+            assert int(extractor.result.proj_iterations) == ref.info["proj_iterations"]
 
 
 @pytest.mark.parametrize("name,points,quads", [("nucleon.mha", 3640, 3636), ("fuel.mha", 1218, 1208),
