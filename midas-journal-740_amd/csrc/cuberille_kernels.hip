@@ -985,10 +985,11 @@ __device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const in
 #pragma unroll
   for (int k = 0; k < 3; k++) cv[k] = p[k] - geo.origin[k];                // I4
   if (unitP2I) {
-    // identity PhysicalPointToIndex matrix: 0 + 1*a + 0*b + 0*c is a + 0 for every a, b, c a vertex
-    // can hold (finite or NaN), including the -0 -> +0 of the leading 0 +
+    // identity PhysicalPointToIndex matrix: 0 + 1*a + 0*b + 0*c is a + 0 for every a, b, c a vertex can hold
+    // (finite or NaN), i.e. a itself except that -0 becomes +0 -- and ci is only used through floor(ci) and
+    // ci - floor(ci), which give the same index and the same +0 fraction for either zero
 #pragma unroll
-    for (int r = 0; r < 3; r++) ci[r] = cv[r] + 0.0;
+    for (int r = 0; r < 3; r++) ci[r] = cv[r];
   } else {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -1002,8 +1003,14 @@ __device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const in
   for (int k = 0; k < 3; k++) {
     const double b = floor(ci[k]);
     c.d[k] = ci[k] - b;
-    c.lo[k] = to_index_clamped(b, n[k] - 1);
-    c.hi[k] = to_index_clamped(b + 1.0, n[k] - 1);
+    // lo = clamp(b, 0, end), hi = clamp(b + 1, 0, end) on integers: the conversion saturates (and sends the NaN of
+    // quirk Q4 to 0, so a NaN vertex still reads inside the image; its coordinates stay NaN whatever it reads)
+    int bi;
+    asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(bi) : "v"(b));
+    const int end = n[k] - 1;
+    const int bc = min(max(bi, -1), end);
+    c.lo[k] = max(bc, 0);
+    c.hi[k] = min(bc + 1, end);
   }
 }
 
@@ -1051,17 +1058,25 @@ __device__ __forceinline__ void gradient_at(const Sampler<T> &s, const Geo &geo,
   gradient_from_taps(geo, dirIdentity, fm, f0, fp, out);
 }
 
+// Register type of the eight cached site values: the walk needs them as doubles; 1- and 2-byte integer pixels are
+// exact in a float, so their cache is half the registers (and is widened at use -- those kernels are short of
+// registers, and their walks are short).
+template <class T>
+struct SiteValue {
+  typedef typename std::conditional<std::is_integral<T>::value && sizeof(T) <= 2, float, double>::type type;
+};
+
 // the eight lattice-site values and gradients of a cell from its gathered 4x4x4 neighbourhood (32 entries used)
 template <class T, bool LITERAL>
 __device__ __forceinline__ void cell_gradients(const Geo &geo, bool dirIdentity, const T (&V)[4][4][4], float G[8][3],
-                                               double Vd[8]) {
+                                               typename SiteValue<T>::type Vd[8]) {
 #pragma unroll
   for (int counter = 0; counter < 8; counter++) {
     const int a = (counter & 1) + 1, b = ((counter >> 1) & 1) + 1, cz = (counter >> 2) + 1;
     const T pix = V[cz][b][a];
     const float fm[3] = {(float)V[cz][b][a - 1], (float)V[cz][b - 1][a], (float)V[cz - 1][b][a]};
     const float fp[3] = {(float)V[cz][b][a + 1], (float)V[cz][b + 1][a], (float)V[cz + 1][b][a]};
-    Vd[counter] = (double)pix;
+    Vd[counter] = (typename SiteValue<T>::type)pix;
     if (LITERAL) {
       gradient_from_taps(geo, dirIdentity, fm, (float)pix, fp, G[counter]);
     } else {
@@ -1094,7 +1109,7 @@ __device__ __forceinline__ void cell_gradients(const Geo &geo, bool dirIdentity,
 // the caller tests for that and gathers again with LITERAL = true.
 template <class T, bool LITERAL>
 __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo, bool dirIdentity, const Cell8 &c,
-                                            float G[8][3], double Vd[8]) {
+                                            float G[8][3], typename SiteValue<T>::type Vd[8]) {
   const bool unit = c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2];
   const int zl = c.lo[2] - s.zglob0;              // buffer slice of the cell's lower z
   if (unit && c.lo[0] >= 1 && c.lo[0] + 2 < s.nx && c.lo[1] >= 1 && c.lo[1] + 2 < s.ny && zl >= 1 && zl + 2 < s.nzb) {
@@ -1150,7 +1165,7 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
       const int ny_ = (counter & 2) ? c.hi[1] : c.lo[1];
       const int nz_ = (counter & 4) ? c.hi[2] : c.lo[2];
       const T pix = s.at(nx_, ny_, nz_);
-      Vd[counter] = (double)pix;
+      Vd[counter] = (typename SiteValue<T>::type)pix;
       gradient_at(s, geo, dirIdentity, nx_, ny_, nz_, (float)pix, G[counter]);
     }
   }
@@ -1199,7 +1214,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   unsigned numberOfSteps = 0;
   int kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};           // cell held in registers
   float G[8][3];
-  double Vd[8];
+  typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
   bool unitP2I = true;
 #pragma unroll
@@ -1240,7 +1255,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         double td = 0.0;
 #pragma unroll
         for (int counter = 0; counter < 8; counter++) {
-          td = __builtin_fma(Vd[counter], 0.0, td);
+          td = __builtin_fma((double)Vd[counter], 0.0, td);
 #pragma unroll
           for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
         }
@@ -1265,9 +1280,9 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         // the weights are >= 0, so the rounded partial sums never decrease: if the sum of the first seven is
         // below 1 none of them is 1 (a sum that is not below 1 -- or NaN -- takes the literal loop, which is
         // always right)
-        double t = 0.0;
+        double t = o[0];
 #pragma unroll
-        for (int counter = 0; counter < 7; counter++) t += o[counter];
+        for (int counter = 1; counter < 7; counter++) t += o[counter];
         literal |= !(t < 1.0);
       }
       double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
@@ -1276,7 +1291,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         for (int counter = 0; counter < 8; counter++) {
 #pragma unroll
           for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
-          value += o[counter] * Vd[counter];
+          value += o[counter] * (double)Vd[counter];
         }
       } else {
         double total = 0.0;
@@ -1285,7 +1300,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           if (o[counter] != 0.0 && total != 1.0) {   // "if (overlap)" + "break once total == 1"
 #pragma unroll
             for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
-            value += o[counter] * Vd[counter];
+            value += o[counter] * (double)Vd[counter];
             total += o[counter];
           }
         }
