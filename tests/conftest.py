@@ -56,6 +56,13 @@ def extractor(pkg):
     ex.close()
 
 
+def point_bytes(points):
+    """As tests/golden/make_mesh_digests.py: float32 bits with every NaN replaced by 0x7fc00000."""
+    bits = points.astype("<f4").view("<u4").copy()
+    bits[np.isnan(points)] = 0x7fc00000
+    return bits.tobytes()
+
+
 def assert_same_mesh(mesh, ref, coords="bits"):
     """GPU mesh vs oracle mesh: identical ids and cell order; coordinates bit-identical
     (or within the stated relative tolerance when coords is a float)."""

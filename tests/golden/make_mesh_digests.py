@@ -5,7 +5,7 @@ ORACLE output, not reference output: the reference cannot be built here (needs I
 nothing but the two counts of ctest_cases.json.  For every Data volume x {quads, triangles} x {projection off,
 on} (CuberilleTest01's CLI defaults otherwise: thr 0.5, step 0.25, relax 0.95, max 50; iso = the first iso the
 reference's CTest table uses for that volume) this stores the counts and SHA-256 digests of the point buffer
-(float32 bits, little endian) and of the cell buffer (uint64 ids).  The digests freeze the oracle (a later
+(float32 bits, little endian, NaNs canonicalised) and of the cell buffer (uint64 ids).  The digests freeze the oracle (a later
 edit that changes any bit of any mesh fails tests/test_oracle.py) and gate the HIP path on boxes where only
 the fixtures travel.
 """
@@ -14,14 +14,24 @@ import json
 import os
 import sys
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import __graft_entry__ as graft  # noqa: E402
 
 
+def point_bytes(points):
+    """float32 bits, little endian, every NaN replaced by the one pattern 0x7fc00000 (the walk of quirk Q4 leaves NaN
+    coordinates whose sign and payload carry no meaning and depend on the machine's NaN propagation)."""
+    bits = points.astype("<f4").view("<u4").copy()
+    bits[np.isnan(points)] = 0x7fc00000
+    return bits.tobytes()
+
+
 def digest(mesh):
     return dict(points=int(mesh.points.shape[0]), cells=int(mesh.cells.shape[0]),
-                points_sha256=hashlib.sha256(mesh.points.astype("<f4").tobytes()).hexdigest(),
+                points_sha256=hashlib.sha256(point_bytes(mesh.points)).hexdigest(),
                 cells_sha256=hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest())
 
 
