@@ -116,6 +116,10 @@ class Extractor:
         s = torch.cuda.current_stream(self.device).cuda_stream
         _abi.check(self._ctx, self._lib.cuberille_set_stream(self._ctx, C.c_void_p(s)))
 
+    def use_own_stream(self):
+        """Back to the context's own stream (the default)."""
+        _abi.check(self._ctx, self._lib.cuberille_set_stream(self._ctx, C.c_void_p(0)))
+
     # -- whole-path entry points -----------------------------------------------------------
     def extract_host(self, vol, params):
         """vol: mha.Volume in host memory.  Upload + extract (PCIe-inclusive)."""

@@ -744,3 +744,33 @@ def test_nonfinite_and_signed_zero_voxels_walk_like_the_oracle(pkg, oracle, extr
             want = oracle.run(vol, iso, **kw, **geo)
             got = run_gpu(pkg, extractor, pkg.Volume(vol, **geo), iso, **kw)
             assert_same_mesh(got, want)
+
+
+def test_caller_stream_orders_the_extraction(pkg, oracle, extractor, volumes):
+    """cuberille_set_stream: with the context on the caller's stream, a volume produced on that stream by
+    asynchronous work (here a long chain of torch kernels ending in the real voxels) needs no host
+    synchronisation before the extraction; afterwards the context goes back to its own stream."""
+    import torch
+    vol = volumes("hydrogenAtom.mha")
+    want = oracle.run(vol.voxels, 15, triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    nx, ny, nz = vol.dims
+    desc = pkg.make_desc(np.uint8, (nx, ny, nz))
+    prm = pkg.make_params(15, triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    host = torch.from_numpy(vol.voxels).pin_memory()
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            extractor.use_torch_stream()
+            dev = torch.zeros((nz, ny, nx), dtype=torch.uint8, device="cuda")
+            big = torch.ones((4096, 4096), device="cuda")
+            for _ in range(20):                       # keep the stream busy so the copy below lands late
+                big = big @ big * 1e-4
+            dev.copy_(host, non_blocking=True)
+            extractor.extract_device(dev.data_ptr(), desc, prm)      # stream-ordered behind the copy
+            mesh = extractor.download()
+    finally:
+        extractor.use_own_stream()
+    assert_same_mesh(mesh, want)
+    torch.cuda.synchronize()
+    extractor.extract_device(dev.data_ptr(), desc, prm)
+    assert_same_mesh(extractor.download(), want)
