@@ -858,7 +858,8 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
 
 // one quad (or its two triangles): corner ids from the dense map, Q1 redirect, fused diagonal split
 template <bool TRI, bool MAP>
-__device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 q, u64 V0) {
+__device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 V0,
+                                              u64 (&o)[TRI ? 6 : 4]) {
   const int zp = a.alias[z];
   u64 lid[4];                                    // vertex index in the counted range
 #pragma unroll
@@ -885,9 +886,8 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
   u64 id[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) id[c] = lid[c] - V0 + a.pointOffset;
-  if (!TRI) {
-    u64 *dst = a.cells + 4 * q;
-    dst[0] = id[0]; dst[1] = id[1]; dst[2] = id[2]; dst[3] = id[3];
+  if constexpr (!TRI) {
+    o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
   } else {
     float v[4][3];
 #pragma unroll
@@ -900,7 +900,6 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
     for (int t = 0; t < 3; t++) { const double d = (double)v[2][t] - (double)v[0][t]; d02 += d * d; }
 #pragma unroll
     for (int t = 0; t < 3; t++) { const double d = (double)v[3][t] - (double)v[1][t]; d13 += d * d; }
-    u64 *o = a.cells + 6 * q;
     if (d02 >= d13) {                                                         // txx:298-302
       o[0] = id[0]; o[1] = id[1]; o[2] = id[3];
       o[3] = id[1]; o[4] = id[2]; o[5] = id[3];
@@ -915,33 +914,57 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
 // (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
 template <bool TRI, bool MAP>
 __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
+  constexpr int NV = TRI ? 6 : 4;                // ids per quad
+  // a lane's NV ids are 32 or 48 contiguous bytes, a wave's 64 quads 2 or 3 KiB: staged through LDS so that the
+  // wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
+  __shared__ u64 stage[4][64 * NV];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 waveFirst = q - lane;
+  if (waveFirst >= nQ) return;                   // wave-uniform
+  const bool valid = q < nQ;
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
   u32 r = 0;
   size_t gi;
-  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a.segBaseQ, a.prefix, a.headQ, nseg, nwords, q + Q0, q < nQ, r);
-  else gi = (q < nQ) ? locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r) : 0;
-  if (q >= nQ) return;
-  int k, y, z;
-  word_coords(g, gi, k, y, z);
-  u64 F[6];
-  faces_word(a.bits, g, y, z, k, F);
-  int lo = 0, hi = 64;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    int c = 0;
+  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a.segBaseQ, a.prefix, a.headQ, nseg, nwords, q + Q0, valid, r);
+  else gi = valid ? locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r) : 0;
+  if (valid) {
+    int k, y, z;
+    word_coords(g, gi, k, y, z);
+    u64 F[6];
+    faces_word(a.bits, g, y, z, k, F);
+    int lo = 0, hi = 64;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      int c = 0;
 #pragma unroll
-    for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
-    if ((u32)c <= r) lo = mid; else hi = mid;
-  }
-  int before = 0;
-  unsigned fm = 0;
+      for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
+      if ((u32)c <= r) lo = mid; else hi = mid;
+    }
+    int before = 0;
+    unsigned fm = 0;
 #pragma unroll
-  for (int f = 0; f < 6; f++) {
-    before += popc64(F[f] & lowmask(lo));
-    fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
+    for (int f = 0; f < 6; f++) {
+      before += popc64(F[f] & lowmask(lo));
+      fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
+    }
+    u64 o[NV];
+    emit_one_cell<TRI, MAP>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), V0, o);
+#pragma unroll
+    for (int i = 0; i < NV; i++) stage[wv][lane * NV + i] = o[i];
   }
-  emit_one_cell<TRI, MAP>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), q, V0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const u64 left = nQ - waveFirst;
+  const unsigned nPairs = (unsigned)(left < 64 ? left : 64) * (NV / 2);      // 16-byte pieces this wave holds
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(stage[wv]);
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.cells + waveFirst * NV);
+#pragma unroll
+  for (int i = 0; i < NV / 2; i++) {
+    const unsigned piece = i * 64 + lane;
+    if (piece < nPairs) dst[piece] = src[piece];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
