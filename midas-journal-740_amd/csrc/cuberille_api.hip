@@ -348,7 +348,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  HIP_TRY(c, launch_heads(w, c->nwords, s));
+  HIP_TRY(c, launch_heads(w, c->nwords, c->tot.totV, c->tot.totQ, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, c->tot.nVertexWords, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));

@@ -76,7 +76,7 @@ struct Params {
 hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, int z0, int z1, hipStream_t s);
 hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s);
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
-hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s);
+hipError_t launch_heads(const Workspace &w, size_t nwords, u64 totV, u64 totQ, hipStream_t s);
 hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s);

@@ -743,6 +743,17 @@ __device__ __forceinline__ size_t locate_word(const u64 *__restrict__ segBase, c
   return wlo;
 }
 
+// head table by search: entry t = the word that produces output 64 t.  One lane per ENTRY (outputs/64 of them)
+// instead of one lane per word of the volume: ~24 dependent L2 reads each, but only a few hundred thousand lanes.
+template <int SHIFT>
+__global__ __launch_bounds__(256) void k_heads_search(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
+                                                      size_t nseg, size_t nwords, u64 nHeads, u32 *__restrict__ head) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nHeads) return;
+  u32 within;
+  head[t] = (u32)locate_word<SHIFT>(segBase, prefix, nseg, nwords, t * 64, within);
+}
+
 // All 64 lanes of the wave must call this together (idx = consecutive outputs, `valid` lanes only).
 template <int SHIFT>
 __device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
@@ -1518,8 +1529,16 @@ hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, si
   return hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, out, (int)n, s);
 }
 
-hipError_t launch_heads(const Workspace &w, size_t nwords, hipStream_t s) {
+hipError_t launch_heads(const Workspace &w, size_t nwords, u64 totV, u64 totQ, hipStream_t s) {
   if (!w.headQ) return hipSuccess;
+  static const int bySearch = getenv("CUBERILLE_HEADS_SWEEP") ? 0 : 1;
+  if (bySearch) {
+    const size_t nseg = (nwords + 63) >> 6;
+    const u64 nHQ = (totQ + 63) / 64, nHV = w.headV ? (totV + 63) / 64 : 0;
+    if (nHQ) hipLaunchKernelGGL((k_heads_search<16>), dim3(grid_for(nHQ, 256, 0)), dim3(256), 0, s, w.segBaseQ, w.prefix, nseg, nwords, nHQ, w.headQ);
+    if (nHV) hipLaunchKernelGGL((k_heads_search<0>), dim3(grid_for(nHV, 256, 0)), dim3(256), 0, s, w.segBaseV, w.prefix, nseg, nwords, nHV, w.headV);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_heads, dim3(grid_for(nwords, 256, 0)), dim3(256), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ,
                      nwords, w.headV, w.headQ);
   return hipGetLastError();
