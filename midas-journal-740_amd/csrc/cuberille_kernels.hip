@@ -855,6 +855,94 @@ __global__ __launch_bounds__(256) void k_emit_points_queue(EmitArgs a, Grid g, G
   }
 }
 
+// K3a, queue form in two phases per wave.  Phase 1, one lane per vertex word: classify, count, wave scan, and a
+// walk that only writes 2-byte descriptors (source lane, voxel, corner) into LDS in id order.  Phase 2, one lane
+// per VERTEX: descriptor -> lattice point, point store (lanes of one word hold consecutive ids: runs of
+// contiguous 12-byte stores), corner-map store.  The point arithmetic and the stores, the expensive part, run on
+// full waves instead of on the few lanes that still have vertices left.  A wave with more vertices than its LDS
+// slice holds (cannot happen on smooth surfaces) walks and stores directly, as k_emit_points_queue does.
+constexpr int POINTS_CAP = 1024;                 // descriptors per wave
+
+__global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, Geo geo, const u32 *__restrict__ vqueue,
+                                                           u32 nVertexWords) {
+  __shared__ unsigned short desc[4][POINTS_CAP];
+  __shared__ int wk[4][64], wy[4][64], wz[4][64];
+  __shared__ u32 woff[4][64];
+  __shared__ u64 wv0[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t - lane >= nVertexWords) return;          // wave-uniform
+  const bool valid = t < nVertexWords;
+  WordInfo w;
+  int k = 0, y = 0, z = 0;
+  u64 v0 = 0;
+  u32 cnt = 0;
+  if (valid) {
+    const u32 gi = vqueue[t];
+    const u32 row = gi / (u32)g.W;
+    k = (int)(gi - row * (u32)g.W);
+    const u32 zz = row / (u32)g.ny;
+    y = (int)(row - zz * (u32)g.ny);
+    z = g.cz0 + (int)zz;
+    classify_word(a.bits, a.alias, g, y, z, k, w);
+    v0 = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);       // id of this word's first vertex
+#pragma unroll
+    for (int i = 0; i < 8; i++) cnt += (u32)popc64(w.C[i]);
+  }
+  u32 incl = cnt;
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) {
+    const u32 up = __shfl_up(incl, sft, 64);
+    if (lane >= sft) incl += up;
+  }
+  const u32 off = incl - cnt;
+  const u32 total = __shfl(incl, 63, 64);
+  const bool dense = total <= (u32)POINTS_CAP;   // wave-uniform
+  if (valid) {
+    u64 any = w.C[0] | w.C[1] | w.C[2] | w.C[3] | w.C[4] | w.C[5] | w.C[6] | w.C[7];
+    u32 j = off;
+    u64 v = v0;
+    while (any) {
+      const int bx = __ffsll((long long)any) - 1;
+      any &= any - 1;
+      unsigned cm = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
+      while (cm) {
+        const int e = kCornerEnc[__ffs((int)cm) - 1];
+        cm &= cm - 1;
+        if (dense) {
+          desc[wv][j++] = (unsigned short)((lane << 9) | (bx << 3) | e);
+        } else {
+          const int cx = k * 64 + bx + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
+          float p[3];
+          corner_point(geo, cx, cy, g.zglob0 + cz, p);
+          float *dst = a.points + 3 * v;
+          dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+          if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
+          v++;
+        }
+      }
+    }
+  }
+  if (!dense) return;
+  wk[wv][lane] = k; wy[wv][lane] = y; wz[wv][lane] = z; woff[wv][lane] = off; wv0[wv][lane] = v0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (u32 i = lane; i < total; i += 64) {
+    const unsigned d = desc[wv][i];
+    const int src = d >> 9, bx = (d >> 3) & 63, e = d & 7;
+    const u64 v = wv0[wv][src] + (i - woff[wv][src]);
+    const int cx = wk[wv][src] * 64 + bx + (e & 1), cy = wy[wv][src] + ((e >> 1) & 1), cz = wz[wv][src] + (e >> 2);
+    float p[3];
+    corner_point(geo, cx, cy, g.zglob0 + cz, p);
+    float *dst = a.points + 3 * v;
+    dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+    if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
+  }
+}
+
 // the six face masks of a word only (7 bit-rows instead of 27)
 __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
   const Rows3 c = load_row(bits, g, y, z, k);
@@ -1565,8 +1653,11 @@ static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s) {
   if (!nV) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 2;
-  if (w.vqueue && nwords < 0xffffffffULL && variant == 2) {
+  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 3;
+  if (w.vqueue && nwords < 0xffffffffULL && variant == 3) {
+    hipLaunchKernelGGL(k_emit_points_dense, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo,
+                       w.vqueue, nVertexWords);
+  } else if (w.vqueue && nwords < 0xffffffffULL && variant == 2) {
     hipLaunchKernelGGL(k_emit_points_queue, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo,
                        w.vqueue, nVertexWords);
   } else if (w.headV && variant >= 1) {
