@@ -1098,6 +1098,7 @@ __device__ __forceinline__ int to_index_clamped(double b, int end) {
 }
 
 struct Cell8 {
+  int bc[3];       // floor of the continuous index clamped to [-1, end]: lo and hi are functions of it
   int lo[3], hi[3];
   double d[3];
 };
@@ -1131,6 +1132,7 @@ __device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const in
     asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(bi) : "v"(b));
     const int end = n[k] - 1;
     const int bc = min(max(bi, -1), end);
+    c.bc[k] = bc;
     c.lo[k] = max(bc, 0);
     c.hi[k] = min(bc + 1, end);
   }
@@ -1334,7 +1336,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   float vertex[3] = {0.f, 0.f, 0.f};
   double step = 0.0;
   unsigned numberOfSteps = 0;
-  int kl[3] = {-1, -1, -1}, kh[3] = {-1, -1, -1};           // cell held in registers
+  int kc[3] = {-2, -2, -2};                        // cell held in registers, named by its clamped floor indices
   float G[8][3];
   typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
@@ -1354,7 +1356,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           vertex[0] = points[3 * idx]; vertex[1] = points[3 * idx + 1]; vertex[2] = points[3 * idx + 2];
           step = prm.step;
           numberOfSteps = 0;
-          kl[0] = -1;
+          kc[0] = -2;
           active = true;
         }
       }
@@ -1367,11 +1369,10 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
       make_cell(geo, unitP2I, n, p, c);
-      if (c.lo[0] != kl[0] || c.lo[1] != kl[1] || c.lo[2] != kl[2] || c.hi[0] != kh[0] || c.hi[1] != kh[1] ||
-          c.hi[2] != kh[2]) {
+      if (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2]) {
         gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { kl[k] = c.lo[k]; kh[k] = c.hi[k]; }
+        for (int k = 0; k < 3; k++) kc[k] = c.bc[k];
         // all 32 cached numbers finite?  x*0 accumulates to 0 for finite x, to NaN for an infinity or a NaN
         float tf = 0.0f;
         double td = 0.0;
