@@ -243,6 +243,18 @@ __global__ void k_alias(const u32 *__restrict__ sliceOcc, int *__restrict__ alia
   alias[z] = a;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP data path (no LDS round trips, unlike __shfl_up):
+// doubling steps inside each row of 16 lanes, then the row totals carried across with row_bcast 15 / 31.
+__device__ __forceinline__ u32 wave_inclusive_sum(u32 v) {
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Word classification: everything a 64-voxel word needs, from the 27 neighbour bit-rows.
 // ---------------------------------------------------------------------------------------------
@@ -457,12 +469,7 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     const size_t gi = w0 + sg * 64 + lane;
     if ((gi & ~(size_t)63) >= nwords) break;    // wave-uniform
     const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
-    u32 incl = packed;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-      const u32 t = __shfl_up(incl, sft, 64);
-      if (lane >= sft) incl += t;
-    }
+    const u32 incl = wave_inclusive_sum(packed);
     if (gi < nwords) prefix[gi] = incl - packed;
     if (lane == 63) {
       segV[gi >> 6] = incl & 0xffffu;
@@ -889,12 +896,7 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt += (u32)popc64(w.C[i]);
   }
-  u32 incl = cnt;
-#pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) {
-    const u32 up = __shfl_up(incl, sft, 64);
-    if (lane >= sft) incl += up;
-  }
+  const u32 incl = wave_inclusive_sum(cnt);
   const u32 off = incl - cnt;
   const u32 total = __shfl(incl, 63, 64);
   const bool dense = total <= (u32)POINTS_CAP;   // wave-uniform
