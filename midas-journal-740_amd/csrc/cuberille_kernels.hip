@@ -774,16 +774,20 @@ __device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBa
   for (int slide = 0; slide < 4; slide++) {
     const size_t w = w0 + lane;
     const u64 A = (w < nwords) ? segBase[w >> 6] + ((prefix[w] >> SHIFT) & 0xffffu) : ~0ull;
-    int lo = 0, hi = 64;                         // largest j with A[j] <= idx
+    // first output of word w relative to the wave's first output: the head word starts at most one word's
+    // worth (< 2^16) below it, everything that matters is <= 63, so 32 bits hold it exactly (large values clamp)
+    const long long rel = (long long)(A - first);
+    const int t = (A == ~0ull || rel > (1 << 20)) ? (1 << 20) : (int)rel;
+    int lo = 0, hi = 64;                         // largest j with t[j] <= lane  (A[j] <= idx)
 #pragma unroll
     for (int st = 0; st < 6; st++) {
       const int mid = (lo + hi) >> 1;
-      const u64 v = __shfl(A, mid, 64);
-      if (v <= idx) lo = mid; else hi = mid;
+      const int v = __shfl(t, mid, 64);
+      if (v <= lane) lo = mid; else hi = mid;
     }
-    const u64 Alo = __shfl(A, lo, 64);
+    const int tlo = __shfl(t, lo, 64);
     // inside the window unless the last loaded word is still <= idx (its successor is unknown)
-    if (!done && lo < 63) { found = w0 + lo; within = (u32)(idx - Alo); done = true; }
+    if (!done && lo < 63) { found = w0 + lo; within = (u32)(lane - tlo); done = true; }
     if (!__ballot(!done)) return found;
     w0 += 63;
   }
