@@ -13,17 +13,20 @@
 //              creates corner i" masks; popcounts + a wavefront scan per 64-word segment
 //                                                                                -> prefix, seg totals
 //   scan     : hipCUB exclusive sum over the per-segment totals                  -> segBase
-//   emit     : one lane per OUTPUT (vertex / quad), located by a per-wave search of the prefix
-//              arrays; points and cells land at their final, reference-order indices; corner ids
-//              through a dense lattice-corner map
+//   emit     : points: one lane per vertex-creating word writes descriptors into LDS, then one lane per
+//              vertex; cells: one lane per output quad, located by a per-wave search of the prefix
+//              arrays, ids staged through LDS; everything lands at its final, reference-order index;
+//              corner ids through a dense lattice-corner map
 //   project  : refilling waves, the damped gradient walk with the gradient image evaluated on the
 //              fly (never materialised); runs between the point and the cell pass so that the
 //              shorter-diagonal triangle split is fused into the cell pass.
 // Bit-exactness of the floating-point part against the CPU oracle relies on
-// -ffp-contract=off (no FMA fusion) and IEEE f64 div/sqrt; see csrc/Makefile.
+// -ffp-contract=off (no FMA fusion; the explicit fma calls in k_project are the compiler's own f64
+// sqrt / division sequences written out) and IEEE f64 arithmetic; see csrc/Makefile.
 // Tuning switches read from the environment (defaults are the measured best): CUBERILLE_PROJ_CHUNK,
 // CUBERILLE_PROJ_WAVES, CUBERILLE_PROJ_REFILL, CUBERILLE_PROJ_XCD, CUBERILLE_PROJ_LITERAL,
-// CUBERILLE_CLASSIFY_VARIANT, CUBERILLE_CLASSIFY_GRID, CUBERILLE_POINTS_VARIANT.
+// CUBERILLE_CLASSIFY_VARIANT, CUBERILLE_CLASSIFY_GRID, CUBERILLE_POINTS_VARIANT, CUBERILLE_HEADS_SWEEP,
+// CUBERILLE_NO_STREAM_CLASSIFY (and the test switches CUBERILLE_NO_CMAP / NO_HEADS / NO_VQUEUE in the host layer).
 
 #include "cuberille_internal.h"
 #include "../../include/cuberille_hip.h"
