@@ -16,9 +16,10 @@
  * There is NO CPU fallback: every entry point that computes returns
  * CUBERILLE_ERR_NO_DEVICE when no gfx950 device is usable.
  *
- * Threading: a context is not thread-safe; distinct contexts are independent.
- * All work is stream-ordered on the context's stream and complete on return unless
- * a function says otherwise.
+ * Threading: a context is not thread-safe; distinct contexts are independent and may be
+ * created, used and destroyed from different threads at the same time (the text of a failed
+ * cuberille_create is kept per thread).  All work is stream-ordered on the context's stream and
+ * complete on return unless a function says otherwise.  The library never reads the environment.
  */
 #ifndef CUBERILLE_HIP_H
 #define CUBERILLE_HIP_H
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 3
+#define CUBERILLE_ABI_VERSION 4
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -84,7 +85,21 @@ typedef struct {
   uint64_t cell_id_offset;  /*   with cuberille_emit after the count all-gather */
   void *halo_ready_event;   /* optional hipEvent_t recorded behind the halo exchange: cuberille_count
                                thresholds the owned slices at once and the halo slices after it */
+  void *voxels_ready_event; /* optional hipEvent_t recorded on the stream that produced the OWNED slices:
+                               nothing of the buffer is read before it (the context runs on its own stream) */
 } cuberille_slab;
+
+/* What a multi-GPU driver needs to know about the last cuberille_count of a slab besides the counts
+ * (it travels in the same all-gather): quirk Q1 re-uses vertices across EMPTY slices, so a rank whose
+ * first occupied slice has only empty slices below it, down to the bottom of its buffer, cannot tell
+ * whether the reference would alias it to something further down -- the ranks below can. */
+typedef struct {
+  int32_t alias_source_below_buffer; /* 1: the count assumed "nothing occupied below my buffer"; wrong if a rank
+                                        below reports an occupied slice */
+  int32_t reserved;
+  int64_t lowest_occupied_z;         /* global z of the lowest / highest owned slice holding an inside voxel, -1: none */
+  int64_t highest_occupied_z;
+} cuberille_slab_status;
 
 typedef struct {
   uint64_t n_points;        /* points this call/rank owns */
@@ -93,8 +108,8 @@ typedef struct {
   int32_t reserved;
   /* device time of each stage in milliseconds (HIP events on the context's stream) */
   float ms_classify;        /* threshold + bit-pack sweep over the volume */
-  float ms_count;           /* per-word face / created-corner counts */
-  float ms_scan;            /* prefix sums */
+  float ms_count;           /* per-word face / created-corner counts and all prefix sums (one kernel) */
+  float ms_scan;            /* 0: the scans run inside the count kernel since ABI 4 (field kept for layout) */
   float ms_emit_points;     /* vertex scatter: AddVertex without the projection (txx:256-276) */
   float ms_project;         /* vertex projection (txx:439-474) */
   float ms_emit_cells;      /* quad / triangle scatter incl. the diagonal split (txx:278-332) */
@@ -116,7 +131,9 @@ void cuberille_destroy(cuberille_ctx *ctx);
 /* run on a caller's hipStream_t instead of the context's own (NULL = back to own) */
 int cuberille_set_stream(cuberille_ctx *ctx, void *hip_stream);
 
-/* One call = GenerateData(): upload `host_voxels`, extract, leave the mesh on the device. */
+/* One call = GenerateData(): upload `host_voxels`, extract, leave the mesh on the device.  Large volumes cross
+ * the link in z-chunks through a pinned double buffer filled by a few host threads, and every chunk is thresholded
+ * while the next one is in flight, so the call takes about bytes / link rate (pageable caller memory included). */
 int cuberille_extract_host(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *host_voxels,
                            const cuberille_params *prm, cuberille_result *res);
 /* Same with the volume already resident in HBM (`dev_voxels` is a device pointer). */
@@ -130,6 +147,13 @@ int cuberille_count(cuberille_ctx *ctx, const cuberille_image_desc *img, const v
                     uint64_t *n_points, uint64_t *n_cells);
 int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, uint64_t cell_id_offset,
                    cuberille_result *res);
+/* Slices a slab buffer must hold below own_z0 and above own_z1 (where the volume does not end) for these
+ * parameters: 2 / 1 for the topology, and as far as the projection walk can carry a vertex -- step *
+ * sum(relaxation^k, k <= max_steps+1) over the z spacing -- plus the interpolation cell and the gradient ring.
+ * cuberille_count returns CUBERILLE_ERR_HALO for a buffer that holds less.  Needs no GPU. */
+int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above);
+/* After cuberille_count on a slab: see cuberille_slab_status. */
+int cuberille_slab_info(cuberille_ctx *ctx, cuberille_slab_status *out);
 
 /* Result buffers of the last extract/emit (valid until the next call on this context):
  * points = float[3*n_points], cells = uint64[verts_per_cell*n_cells] holding GLOBAL point ids. */
@@ -137,8 +161,10 @@ int cuberille_mesh_device(const cuberille_ctx *ctx, const float **d_points, cons
 int cuberille_mesh_download(cuberille_ctx *ctx, float *points, uint64_t *cells);
 
 /* Flat-mesh file output (replaces the itk::Mesh fill + itk::VTKPolyDataWriter pass of
- * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA,
- * byte-identical to what that writer produces for the same mesh, formatted by `n_threads` host threads
+ * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA in
+ * the layout of that writer (header lines, "POINTS n float", "POLYGONS m k"), coordinates with 9 significant
+ * digits.  Checked byte for byte against the itk_lite writer shipped in this repository; ITK's own writer was
+ * never run here, so equality with ITK's bytes (its number formatting) is unpinned.  Formatted by `n_threads` host threads
  * (0 = one per core, at most 32).  The first form writes host buffers and needs no GPU (multi-GPU: rank 0
  * passes the rank-ordered concatenation, whose ids are already global); the second downloads the context's
  * last mesh first and refuses a slab mesh (its cells reference points of the rank below). */
@@ -152,6 +178,10 @@ int cuberille_debug_bits(cuberille_ctx *ctx, uint64_t *words, size_t n_words);
 /* Per buffer slice: non-zero when the slice holds at least one inside voxel.  The multi-GPU
  * driver gathers these to detect the empty-slice aliasing quirk (Q1) crossing a slab boundary. */
 int cuberille_slice_occupancy(cuberille_ctx *ctx, uint32_t *occupied, size_t n_slices);
+/* Development switches of one context (kernel variants, dropping a scratch table to exercise the fallback
+ * path): name = a field of cuberille::Tuning (csrc/cuberille_internal.h), or "defaults" to reset them all.
+ * Results never depend on them, only speed and memory.  Used by the parity tests and the ablation scripts. */
+int cuberille_debug_set_option(cuberille_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus
 }

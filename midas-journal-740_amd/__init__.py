@@ -12,5 +12,5 @@ The directory name carries a hyphen, so import it through `__graft_entry__.load_
   itk/             C++ drop-in: itkCuberilleImageToMeshFilter.h + the ITK-lite shim headers
 """
 from . import _abi, mha, volumes  # noqa: F401
-from .cuberille import CuberilleImageToMeshFilter, Extractor, Mesh, make_desc, make_params  # noqa: F401
+from .cuberille import CuberilleImageToMeshFilter, Extractor, Mesh, make_desc, make_params, required_halo  # noqa: F401
 from .mha import Volume, read_mha, write_mha  # noqa: F401

@@ -21,7 +21,9 @@ EXPORTS = [
     "cuberille_destroy", "cuberille_set_stream", "cuberille_extract_host", "cuberille_extract_device",
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
+    "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option",
 ]
+ABI_VERSION = 4
 
 
 class ImageDesc(C.Structure):
@@ -37,7 +39,13 @@ class Params(C.Structure):
 
 class Slab(C.Structure):
     _fields_ = [("global_nz", C.c_int64), ("z_begin", C.c_int64), ("own_z0", C.c_int64), ("own_z1", C.c_int64),
-                ("point_id_offset", C.c_uint64), ("cell_id_offset", C.c_uint64), ("halo_ready_event", C.c_void_p)]
+                ("point_id_offset", C.c_uint64), ("cell_id_offset", C.c_uint64), ("halo_ready_event", C.c_void_p),
+                ("voxels_ready_event", C.c_void_p)]
+
+
+class SlabStatus(C.Structure):
+    _fields_ = [("alias_source_below_buffer", C.c_int32), ("reserved", C.c_int32), ("lowest_occupied_z", C.c_int64),
+                ("highest_occupied_z", C.c_int64)]
 
 
 class Result(C.Structure):
@@ -105,6 +113,9 @@ def lib():
     L.cuberille_slice_occupancy.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_write_vtk_buffers.argtypes = [C.c_char_p, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int]
     L.cuberille_mesh_write_vtk.argtypes = [vp, C.c_char_p, C.c_int]
+    L.cuberille_required_halo.argtypes = [C.POINTER(ImageDesc), C.POINTER(Params), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cuberille_slab_info.argtypes = [vp, C.POINTER(SlabStatus)]
+    L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     _lib = L
     return L
 

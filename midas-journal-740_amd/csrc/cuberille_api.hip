@@ -9,18 +9,22 @@
 #include "../../include/cuberille_hip.h"
 #include "cuberille_internal.h"
 
+#include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace cuberille;
 
 namespace {
 
-std::string g_create_error;
+// text of the last failed cuberille_create on this thread (contexts are independent; so are their creators)
+thread_local std::string g_create_error;
 
 struct DevBuf {
   void *p = nullptr;
@@ -44,9 +48,17 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, flatBits, occ, alias, prefix, segV, segQ, segBaseV, segBaseQ, scanTemp, totals, points, cells, cmap, headV, headQ, vqueue;
+  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, totals, points, cells, cmap, headV, headQ, vqueue,
+      survivors, walkState;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
+  Tuning tune;                           // development switches (cuberille_debug_set_option)
+  // overlapped ingestion (cuberille_extract_host): pinned staging ring and a copy stream
+  hipStream_t copyStream = nullptr;
+  void *stage[2] = {nullptr, nullptr};
+  size_t stageBytes = 0;
+  hipEvent_t stageFree[2] = {}, chunkIn[2] = {};
+  bool aliasBelowBuffer = false;         // soft condition of the last slab count (cuberille_slab_info)
   // state of the last count
   bool counted = false, haveMesh = false, slabMesh = false;
   Grid g{};
@@ -168,11 +180,19 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own) (void)hipStreamSynchronize(c->own);
-  DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->occ, &c->alias, &c->prefix, &c->segV, &c->segQ, &c->segBaseV,
-                    &c->segBaseQ, &c->scanTemp, &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
+  if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
+  DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
+                    &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->survivors,
+                    &c->walkState};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
+  for (int i = 0; i < 2; i++) {
+    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+    if (c->stageFree[i]) (void)hipEventDestroy(c->stageFree[i]);
+    if (c->chunkIn[i]) (void)hipEventDestroy(c->chunkIn[i]);
+  }
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
   if (c->own) (void)hipStreamDestroy(c->own);
   delete c;
 }
@@ -183,12 +203,57 @@ int cuberille_set_stream(cuberille_ctx *c, void *hip_stream) {
   return CUBERILLE_OK;
 }
 
-int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
-                    const cuberille_params *prm, const cuberille_slab *slab, uint64_t *n_points, uint64_t *n_cells) {
-  int rc = validate(c, img, dev_voxels, prm);
-  if (rc) return rc;
+}  // extern "C"
+
+namespace {
+
+// How far, in slices, the projection can carry a vertex away from the slice it was created in, plus the cell's
+// upper neighbour, the gradient ring and rounding: what a slab must hold beyond its owned range on each side.
+// The walk moves at most step * sum(relax^k, k = 0 .. max_steps+1) in physical space (txx:449-470); the row of
+// PhysicalPointToIndex for z turns that into slices.
+long long projection_reach(const Geo &geo, const Params &p) {
+  if (!p.project) return 0;
+  const double n = (double)p.max_steps + 2.0;
+  double travel;
+  if (p.relax >= 1.0) travel = p.step * n;
+  else if (p.relax <= 0.0) travel = p.step;
+  else travel = p.step * (1.0 - std::pow(p.relax, n)) / (1.0 - p.relax);
+  const double rowNorm = std::sqrt(geo.p2i[6] * geo.p2i[6] + geo.p2i[7] * geo.p2i[7] + geo.p2i[8] * geo.p2i[8]);
+  const double slices = std::ceil(travel * rowNorm);
+  if (!(slices < 1e9)) return 1000000000LL;
+  return (long long)slices + 3;
+}
+
+void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &geo, Params &p) {
+  // geometry and parameters (txx:75-85)
+  double maxSpacing = img->spacing[0];
+  for (int i = 0; i < 3; i++) {
+    geo.spacing[i] = img->spacing[i];
+    geo.origin[i] = img->origin[i];
+    geo.gcoef[i] = (float)(0.5 * (1.0 / img->spacing[i]));
+    if (img->spacing[i] > maxSpacing) maxSpacing = img->spacing[i];
+  }
+  for (int i = 0; i < 9; i++) geo.dir[i] = img->direction[i];
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 3; k++) geo.i2p[r * 3 + k] = geo.dir[r * 3 + k] * geo.spacing[k];
+  invert3(geo.i2p, geo.p2i);
+  p.iso = prm->iso_value;
+  p.thr = prm->distance_threshold;
+  p.step = prm->step_length < 0.0 ? maxSpacing * 0.25 : prm->step_length;
+  p.relax = prm->relaxation;
+  p.max_steps = prm->max_steps;
+  p.triangles = prm->generate_triangles != 0;
+  p.project = prm->project_vertices != 0;
+  p.q1 = prm->emulate_empty_slice_aliasing != 0;
+}
+
+// First half of a count: layout, parameters, workspace, zeroed state.  The caller then thresholds the slices
+// (all at once, or z-range by z-range as they arrive) and calls count_finish.
+int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
+                  const cuberille_slab *slab) {
   c->counted = false;
   c->haveMesh = false;
+  c->aliasBelowBuffer = false;
   HIP_TRY(c, hipSetDevice(c->device));
 
   // ---- layout -----------------------------------------------------------------------------
@@ -201,6 +266,9 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
     if (g.W == (1 << b)) g.wShift = b;
     if (g.ny == (1 << b)) g.yShift = b;
   }
+  Geo geo{};
+  Params p{};
+  resolve(img, prm, geo, p);
   const bool whole = !slab || (slab->global_nz == 0 && slab->z_begin == 0 && slab->own_z0 == 0 && slab->own_z1 == 0);   // (all-zero slab = whole volume)
   if (whole) {
     g.gnz = g.nzb; g.zglob0 = 0; g.oz0 = 0; g.oz1 = g.nzb;
@@ -209,11 +277,19 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
         slab->own_z0 < slab->z_begin || slab->own_z1 > slab->z_begin + g.nzb || slab->own_z0 >= slab->own_z1)
       return fail(c, CUBERILLE_ERR_ARGUMENT, "slab ranges are inconsistent with the buffer");
     // the owned range needs 2 slices below (ids of corners created one slice down depend on the
-    // slice below that) and 1 above, unless the volume ends there
-    const long long needLo = slab->own_z0 >= 2 ? slab->own_z0 - 2 : 0;
-    const long long needHi = slab->own_z1 < slab->global_nz ? slab->own_z1 + 1 : slab->global_nz;
-    if (slab->z_begin > needLo || slab->z_begin + g.nzb < needHi)
-      return fail(c, CUBERILLE_ERR_HALO, "slab buffer must hold 2 halo slices below and 1 above the owned range");
+    // slice below that) and 1 above; with the projection on, as far as a walk can reach (both unless the
+    // volume ends there)
+    long long halo = projection_reach(geo, p);
+    const long long lo = halo > 2 ? halo : 2, hi = halo > 1 ? halo : 1;
+    const long long needLo = slab->own_z0 >= lo ? slab->own_z0 - lo : 0;
+    const long long needHi = slab->own_z1 + hi < slab->global_nz ? slab->own_z1 + hi : slab->global_nz;
+    if (slab->z_begin > needLo || slab->z_begin + g.nzb < needHi) {
+      char msg[256];
+      snprintf(msg, sizeof msg, "slab buffer must hold %lld halo slices below and %lld above the owned range for these "
+               "parameters (cuberille_required_halo); it holds %lld and %lld", lo, hi,
+               (long long)(slab->own_z0 - slab->z_begin), (long long)(slab->z_begin + g.nzb - slab->own_z1));
+      return fail(c, CUBERILLE_ERR_HALO, msg);
+    }
     g.gnz = slab->global_nz; g.zglob0 = slab->z_begin;
     g.oz0 = (int)(slab->own_z0 - slab->z_begin);
     g.oz1 = (int)(slab->own_z1 - slab->z_begin);
@@ -223,42 +299,16 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   const size_t nwordsAll = nrowsAll * g.W;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   const size_t nseg = (nwords + 63) / 64;
+  const size_t nblk = (nwords + COUNT_WB - 1) / COUNT_WB;
   if (nseg > 0x7fffffffULL) return fail(c, CUBERILLE_ERR_LIMIT, "volume too large for one device scan");
-
-  // ---- geometry and parameters (txx:75-85) ----------------------------------------------------
-  Geo geo{};
-  double maxSpacing = img->spacing[0];
-  for (int i = 0; i < 3; i++) {
-    geo.spacing[i] = img->spacing[i];
-    geo.origin[i] = img->origin[i];
-    geo.gcoef[i] = (float)(0.5 * (1.0 / img->spacing[i]));
-    if (img->spacing[i] > maxSpacing) maxSpacing = img->spacing[i];
-  }
-  for (int i = 0; i < 9; i++) geo.dir[i] = img->direction[i];
-  for (int r = 0; r < 3; r++)
-    for (int k = 0; k < 3; k++) geo.i2p[r * 3 + k] = geo.dir[r * 3 + k] * geo.spacing[k];
-  invert3(geo.i2p, geo.p2i);
-  Params p{};
-  p.iso = prm->iso_value;
-  p.thr = prm->distance_threshold;
-  p.step = prm->step_length < 0.0 ? maxSpacing * 0.25 : prm->step_length;
-  p.relax = prm->relaxation;
-  p.max_steps = prm->max_steps;
-  p.triangles = prm->generate_triangles != 0;
-  p.project = prm->project_vertices != 0;
-  p.q1 = prm->emulate_empty_slice_aliasing != 0;
 
   // ---- workspace ----------------------------------------------------------------------------------
   HIP_TRY(c, c->bits.reserve(nwordsAll * sizeof(u64)));
   HIP_TRY(c, c->occ.reserve((size_t)g.nzb * sizeof(u32)));
-  HIP_TRY(c, c->alias.reserve((size_t)g.nzb * sizeof(int)));
   HIP_TRY(c, c->prefix.reserve(nwords * sizeof(u32)));
-  HIP_TRY(c, c->segV.reserve(nseg * sizeof(u64)));
-  HIP_TRY(c, c->segQ.reserve(nseg * sizeof(u64)));
-  HIP_TRY(c, c->segBaseV.reserve(nseg * sizeof(u64)));
-  HIP_TRY(c, c->segBaseQ.reserve(nseg * sizeof(u64)));
-  const size_t tempBytes = scan_temp_bytes(nseg);
-  HIP_TRY(c, c->scanTemp.reserve(tempBytes));
+  HIP_TRY(c, c->segPre.reserve(nseg * sizeof(u64)));
+  HIP_TRY(c, c->blockTot.reserve(nblk * sizeof(u64)));
+  HIP_TRY(c, c->blockBase.reserve(nblk * 2 * sizeof(u64)));
   Workspace w{};
   w.flatBits = nullptr;
   if (g.nx % 64 != 0) {   // ragged rows: thresholded as one flat stream first, then cut into rows
@@ -266,55 +316,86 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
     else (void)hipGetLastError();
   }
   w.vqueue = nullptr;
-  if (nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_VQUEUE") && c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess)
+  if (nwords < 0xffffffffULL && !c->tune.no_vqueue && c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess)
     w.vqueue = (u32 *)c->vqueue.p;
   else (void)hipGetLastError();
   w.vox = dev_voxels;
-  w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)c->occ.p; w.alias = (int *)c->alias.p;
+  w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)c->occ.p;
   w.prefix = (u32 *)c->prefix.p;
-  w.segV = (u64 *)c->segV.p; w.segQ = (u64 *)c->segQ.p;
-  w.segBaseV = (u64 *)c->segBaseV.p; w.segBaseQ = (u64 *)c->segBaseQ.p;
+  w.segPre = (u64 *)c->segPre.p; w.blockTot = (u64 *)c->blockTot.p; w.blockBase = (u64 *)c->blockBase.p;
   w.totals = (Totals *)c->totals.p;
 
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(w.sliceOcc, 0, (size_t)g.nzb * sizeof(u32), s));
   HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals), s));
   HIP_TRY(c, hipEventRecord(c->ev[0], s));
-  if (!whole && slab->halo_ready_event && (g.oz0 > 0 || g.oz1 < g.nzb)) {
-    // the caller's halo exchange is still in flight: threshold the owned slices now, the halo
-    // slices once the event it recorded behind the exchange has fired (DESIGN.md section 6)
-    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, g.oz0, g.oz1, s));
-    HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->halo_ready_event, 0));
-    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, 0, g.oz0, s));
-    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, g.oz1, g.nzb, s));
-  } else {
-    HIP_TRY(c, launch_classify(img->pixel_type, w, g, p.iso, 0, g.nzb, s));
-  }
+  c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
+  c->nwords = nwords; c->nseg = nseg;
+  return CUBERILLE_OK;
+}
+
+// Second half: count + scan of the thresholded volume, totals to the host.
+int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
+  hipStream_t s = c->stream;
+  const Grid &g = c->g;
+  const Workspace &w = c->w;
   HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  HIP_TRY(c, launch_alias(w, g, p.q1, s));
-  HIP_TRY(c, launch_count(w, g, nwords, s));
+  HIP_TRY(c, launch_occupancy(w, g, s));
+  HIP_TRY(c, launch_count(w, g, c->nwords, c->prm.q1, s));
   HIP_TRY(c, hipEventRecord(c->ev[2], s));
-  HIP_TRY(c, launch_scan(c->scanTemp.p, tempBytes, w.segV, w.segBaseV, nseg, s));
-  HIP_TRY(c, launch_scan(c->scanTemp.p, tempBytes, w.segQ, w.segBaseQ, nseg, s));
-  HIP_TRY(c, launch_finalize(w, g, nwords, s));
-  HIP_TRY(c, hipEventRecord(c->ev[3], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->tot = *c->hostTotals;
   if (c->tot.err & ERRF_ALIAS_UNKNOWN)
     return fail(c, CUBERILLE_ERR_HALO,
-                "an empty slice makes the reference re-use vertices created below this slab's halo (DESIGN.md Q1)");
-
-  c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
-  c->nwords = nwords; c->nseg = nseg;
+                "an empty slice makes the reference re-use vertices created below this slab's counted range (DESIGN.md Q1)");
+  c->aliasBelowBuffer = (c->tot.err & ERRF_ALIAS_BELOW_BUFFER) != 0;
   c->counted = true;
   std::memset(&c->res, 0, sizeof(c->res));
   c->res.n_points = c->tot.totV - c->tot.V0;
-  c->res.n_cells = (c->tot.totQ - c->tot.Q0) * (p.triangles ? 2 : 1);
-  c->res.verts_per_cell = p.triangles ? 3 : 4;
+  c->res.n_cells = (c->tot.totQ - c->tot.Q0) * (c->prm.triangles ? 2 : 1);
+  c->res.verts_per_cell = c->prm.triangles ? 3 : 4;
   if (n_points) *n_points = c->res.n_points;
   if (n_cells) *n_cells = c->res.n_cells;
   return CUBERILLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above) {
+  if (!img || !prm) return CUBERILLE_ERR_ARGUMENT;
+  for (int i = 0; i < 3; i++) if (!(img->spacing[i] > 0.0)) return CUBERILLE_ERR_ARGUMENT;
+  Geo geo{};
+  Params p{};
+  resolve(img, prm, geo, p);
+  const long long halo = projection_reach(geo, p);
+  if (below) *below = halo > 2 ? halo : 2;
+  if (above) *above = halo > 1 ? halo : 1;
+  return CUBERILLE_OK;
+}
+
+int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
+                    const cuberille_params *prm, const cuberille_slab *slab, uint64_t *n_points, uint64_t *n_cells) {
+  int rc = validate(c, img, dev_voxels, prm);
+  if (rc) return rc;
+  rc = count_prepare(c, img, dev_voxels, prm, slab);
+  if (rc) return rc;
+  const Grid &g = c->g;
+  hipStream_t s = c->stream;
+  if (slab && slab->voxels_ready_event) HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->voxels_ready_event, 0));
+  if (slab && slab->halo_ready_event && (g.oz0 > 0 || g.oz1 < g.nzb)) {
+    // the caller's halo exchange is still in flight: threshold the owned slices now, the halo
+    // slices once the event it recorded behind the exchange has fired (DESIGN.md section 6)
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, g.oz0, g.oz1, c->tune, s));
+    HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->halo_ready_event, 0));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, 0, g.oz0, c->tune, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, g.oz1, g.nzb, c->tune, s));
+  } else {
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, 0, g.nzb, c->tune, s));
+  }
+  return count_finish(c, n_points, n_cells);
 }
 
 int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
@@ -334,26 +415,36 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   // dense corner -> vertex map (4 B per lattice corner of the buffer); when it cannot be had
   // (more than 2^32 vertices, or no memory) the cell kernel recomputes ids instead
   w.cmap = nullptr;
-  if (nV < 0xffffffffULL && !getenv("CUBERILLE_NO_CMAP")) {   // (the variable exists for the tests of the fallback)
+  if (nV < 0xffffffffULL && !c->tune.no_cmap) {
     const size_t mapBytes = (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 1) * sizeof(u32);
     if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
     else (void)hipGetLastError();
   }
   // head tables for the per-wave inverse mapping (4 B per 64 outputs)
   w.headV = w.headQ = nullptr;
-  if (c->nwords < 0xffffffffULL && !getenv("CUBERILLE_NO_HEADS")) {
+  if (c->nwords < 0xffffffffULL && !c->tune.no_heads) {
     if (c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) w.headQ = (u32 *)c->headQ.p;
     if (!w.vqueue && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess) w.headV = (u32 *)c->headV.p;
     (void)hipGetLastError();
   }
+  // projection: survivor list of the dense first phase (4 B + 8 B per vertex at most)
+  w.survivors = nullptr;
+  w.walkState = nullptr;
+  if (c->prm.project && c->tune.proj_phase_a && nV < 0xffffffffULL) {
+    if (c->survivors.reserve((size_t)(nV ? nV : 1) * sizeof(u32)) == hipSuccess &&
+        c->walkState.reserve((size_t)(nV ? nV : 1) * 2 * sizeof(float)) == hipSuccess) {
+      w.survivors = (u32 *)c->survivors.p;
+      w.walkState = (float *)c->walkState.p;
+    } else (void)hipGetLastError();
+  }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  HIP_TRY(c, launch_heads(w, c->nwords, c->tot.totV, c->tot.totQ, s));
-  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, nV, c->tot.nVertexWords, s));
+  HIP_TRY(c, launch_heads(w, c->g, c->tot.totV, c->tot.totQ, s));
+  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, c->tot.nVertexWords, c->tune, s));
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
-  if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, s));
+  if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, s));
   HIP_TRY(c, hipEventRecord(c->ev[6], s));
-  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, point_id_offset, nQ, s));
+  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -361,12 +452,12 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   cuberille_result &r = c->res;
   HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_scan, c->ev[2], c->ev[3]));
+  r.ms_scan = 0.0f;                          // the scans run inside the count kernel (its last block)
   HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
   HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->ev[6], c->ev[7]));
   float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[3]));
+  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[2]));
   HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
   r.ms_total = a + b;                        // device time; excludes the host gap between count and emit
   r.proj_iterations = c->tot.iters;
@@ -384,15 +475,135 @@ int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, 
   return cuberille_emit(c, slab ? slab->point_id_offset : 0, slab ? slab->cell_id_offset : 0, res);
 }
 
+}  // extern "C"
+
+namespace {
+
+// Host threads that copy pageable caller memory into the pinned staging ring, one fixed share of every chunk
+// each (a single memcpy stream cannot feed a PCIe Gen5 link; a handful can).
+struct StagePool {
+  std::vector<std::thread> workers;
+  std::atomic<long long> freeUpTo{-1};      // chunks whose staging slot may be overwritten: all i <= freeUpTo
+  std::vector<std::atomic<int>> done;       // per chunk: workers that have copied their share
+  explicit StagePool(size_t nchunks) : done(nchunks) { for (auto &d : done) d.store(0); }
+};
+
+}  // namespace
+
+extern "C" {
+
 int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, const void *host_voxels,
                            const cuberille_params *prm, cuberille_result *res) {
   int rc = validate(c, img, host_voxels, prm);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
-  const size_t bytes = (size_t)img->dims[0] * img->dims[1] * img->dims[2] * pixel_size(img->pixel_type);
+  const size_t psz = pixel_size(img->pixel_type);
+  const size_t sliceBytes = (size_t)img->dims[0] * img->dims[1] * psz;
+  const size_t nz = (size_t)img->dims[2];
+  const size_t bytes = sliceBytes * nz;
   HIP_TRY(c, c->voxOwn.reserve(bytes));
-  HIP_TRY(c, hipMemcpyAsync(c->voxOwn.p, host_voxels, bytes, hipMemcpyHostToDevice, c->stream));
-  return cuberille_extract_device(c, img, c->voxOwn.p, prm, nullptr, res);
+  // small volumes: one plain copy (the runtime stages pageable memory itself); the extraction follows on the stream
+  const size_t kChunk = 32u << 20;
+  if (bytes < 4 * kChunk || sliceBytes > kChunk) {
+    HIP_TRY(c, hipMemcpyAsync(c->voxOwn.p, host_voxels, bytes, hipMemcpyHostToDevice, c->stream));
+    return cuberille_extract_device(c, img, c->voxOwn.p, prm, nullptr, res);
+  }
+  // large volumes: z-chunks through a pinned double buffer on a copy stream; chunk i is thresholded on the
+  // context's stream while chunk i+1 crosses the link and the host threads stage chunk i+2
+  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  if (c->stageBytes < kChunk) {
+    for (int i = 0; i < 2; i++) {
+      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+      HIP_TRY(c, hipHostMalloc(&c->stage[i], kChunk, hipHostMallocDefault));
+      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
+      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
+    }
+    c->stageBytes = kChunk;
+  }
+  rc = count_prepare(c, img, c->voxOwn.p, prm, nullptr);
+  if (rc) return rc;
+  const size_t slicesPerChunk = kChunk / sliceBytes;
+  const size_t nchunks = (nz + slicesPerChunk - 1) / slicesPerChunk;
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nT = (int)(hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1));
+  StagePool pool(nchunks);
+  const char *src = (const char *)host_voxels;
+  auto chunkRange = [&](size_t i, size_t &z0, size_t &z1) { z0 = i * slicesPerChunk; z1 = z0 + slicesPerChunk < nz ? z0 + slicesPerChunk : nz; };
+  std::atomic<bool> abort{false};
+  for (int t = 0; t < nT; t++) {
+    pool.workers.emplace_back([&, t] {
+      for (size_t i = 0; i < nchunks && !abort.load(std::memory_order_relaxed); i++) {
+        while (pool.freeUpTo.load(std::memory_order_acquire) < (long long)i) {
+          if (abort.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
+        size_t z0, z1;
+        chunkRange(i, z0, z1);
+        const size_t cb = (z1 - z0) * sliceBytes;
+        const size_t a = cb * t / nT & ~(size_t)63, b = (t == nT - 1) ? cb : (cb * (t + 1) / nT & ~(size_t)63);
+        std::memcpy((char *)c->stage[i & 1] + a, src + z0 * sliceBytes + a, b - a);
+        pool.done[i].fetch_add(1, std::memory_order_release);
+      }
+    });
+  }
+  auto joinAll = [&] { for (auto &w : pool.workers) if (w.joinable()) w.join(); };
+  hipError_t e = hipSuccess;
+  pool.freeUpTo.store(1, std::memory_order_release);          // both slots start free
+  for (size_t i = 0; i < nchunks && e == hipSuccess; i++) {
+    while (pool.done[i].load(std::memory_order_acquire) < nT) std::this_thread::yield();
+    size_t z0, z1;
+    chunkRange(i, z0, z1);
+    e = hipMemcpyAsync((char *)c->voxOwn.p + z0 * sliceBytes, c->stage[i & 1], (z1 - z0) * sliceBytes, hipMemcpyHostToDevice,
+                       c->copyStream);
+    if (e == hipSuccess) e = hipEventRecord(c->chunkIn[i & 1], c->copyStream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->chunkIn[i & 1], 0);
+    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm.iso, (int)z0, (int)z1, c->tune, c->stream);
+    // slot (i & 1) is free for chunk i + 2 once this chunk has crossed the link
+    if (e == hipSuccess && i + 2 < nchunks) {
+      e = hipEventSynchronize(c->chunkIn[i & 1]);
+      pool.freeUpTo.store((long long)i + 2, std::memory_order_release);
+    }
+  }
+  if (e != hipSuccess) abort.store(true);
+  joinAll();
+  if (e != hipSuccess) return fail(c, CUBERILLE_ERR_HIP, std::string("overlapped upload: ") + hipGetErrorString(e));
+  uint64_t np = 0, nc = 0;
+  rc = count_finish(c, &np, &nc);
+  if (rc) return rc;
+  return cuberille_emit(c, 0, 0, res);
+}
+
+int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
+  if (!c || !out) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no counted volume on this context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<uint32_t> occ((size_t)c->g.nzb);
+  HIP_TRY(c, hipMemcpyAsync(occ.data(), c->occ.p, occ.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->alias_source_below_buffer = c->aliasBelowBuffer ? 1 : 0;
+  out->lowest_occupied_z = out->highest_occupied_z = -1;
+  for (int z = c->g.oz0; z < c->g.oz1; z++)
+    if (occ[(size_t)z]) {
+      if (out->lowest_occupied_z < 0) out->lowest_occupied_z = c->g.zglob0 + z;
+      out->highest_occupied_z = c->g.zglob0 + z;
+    }
+  return CUBERILLE_OK;
+}
+
+static bool set_opt(Tuning &t, const char *name, long long v) {
+#define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
+  OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
+  OPT(points_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(proj_phase_a)
+  OPT(proj_a_iters)
+#undef OPT
+  return false;
+}
+
+int cuberille_debug_set_option(cuberille_ctx *c, const char *name, int64_t value) {
+  if (!c || !name) return CUBERILLE_ERR_ARGUMENT;
+  if (!std::strcmp(name, "defaults")) { c->tune = Tuning(); return CUBERILLE_OK; }
+  if (!set_opt(c->tune, name, (long long)value)) return fail(c, CUBERILLE_ERR_ARGUMENT, std::string("unknown option ") + name);
+  return CUBERILLE_OK;
 }
 
 int cuberille_mesh_device(const cuberille_ctx *c, const float **d_points, const uint64_t **d_cells) {

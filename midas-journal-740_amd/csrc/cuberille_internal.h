@@ -38,31 +38,56 @@ struct Grid {
   long long gnz;       // global Nz
 };
 
-struct Totals {        // device-resident, mirrored to pinned host memory
+struct Totals {        // device-resident, zeroed before every count, mirrored to pinned host memory
   u64 totV, totQ;      // created vertices / quads in the counted range
   u64 V0, Q0;          // of which before the first owned slice
   u64 iters;           // projection iterations (atomic)
+  u64 g0pre;           // in-block prefix (V | Q << 32) at the first owned word, left by the count block that holds it
   u32 err;             // device-side error flags
-  u32 nVertexWords;   // entries in the vertex-word queue (words that create at least one vertex)
+  u32 nVertexWords;    // entries in the vertex-word queue (words that create at least one vertex)
+  u32 ticket;          // count blocks that have published their totals (the last one scans them)
+  u32 nSurvivors;      // projection: vertices the dense first phase handed on to the refilling walk
 };
 
-enum { ERRF_ALIAS_UNKNOWN = 1 };
+enum {
+  ERRF_ALIAS_UNKNOWN = 1,        // quirk Q1: the aliased source slice is in the buffer but below the counted range
+  ERRF_ALIAS_BELOW_BUFFER = 2    // quirk Q1: the search for the source slice ran off the bottom of a slab buffer
+};
+
+// A count block owns COUNT_WB consecutive words of the flat raster order = 32 scan segments of 64 words.
+// Absolute exclusive prefix of word gi = blockBase[gi >> COUNT_LG] + segPre[gi >> 6] + prefix[gi].
+constexpr int COUNT_LG = 11;
+constexpr int COUNT_WB = 1 << COUNT_LG;
 
 struct Workspace {     // device pointers valid for one count/emit pair
   const void *vox;
   u64 *bits;
   u64 *flatBits;       // scratch for rows that are not whole words: inside bits in flat voxel order (or null)
-  u32 *sliceOcc;
-  int *alias;          // per local slice: source slice of the empty-slice aliasing or -1
+  u32 *sliceOcc;       // per buffer slice: does it hold an inside voxel (quirk Q1 needs it)
   u32 *prefix;         // per counted word: exclusive in-segment prefix, V | Q<<16
-  u64 *segV, *segQ;    // per 64-word segment totals
-  u64 *segBaseV, *segBaseQ;
+  u64 *segPre;         // per 64-word segment: exclusive in-block prefix, V | Q<<32
+  u64 *blockTot;       // per count block: its totals V | Q<<32, published with agent-scope atomics
+  u64 *blockBase;      // per count block: absolute exclusive prefixes, [2b] = V, [2b+1] = Q (written by the last block)
   Totals *totals;
   float *points;
   u64 *cells;
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
   u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
   u32 *vqueue;         // counted-range indices of the words that create vertices, in no particular order (or null)
+  u32 *survivors;      // projection: indices of the vertices still walking after the dense first phase (or null)
+  float *walkState;    // projection: per survivor, step length and loop counter carried over (2 x 4 B)
+};
+
+// Development switches, set per context through cuberille_debug_set_option (never read from the environment).
+// The defaults are the measured best; the parity tests flip the fallbacks on to cover them.
+struct Tuning {
+  int no_cmap = 0, no_heads = 0, no_vqueue = 0, no_stream_classify = 0;   // drop a scratch table / the flat-stream path
+  int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
+  int classify_grid = 0;      // workgroups of the sweep (0 = default)
+  int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
+  int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
+  int proj_phase_a = 1;       // dense in-cell first phase before the refilling walk (0 = refilling walk only)
+  int proj_a_iters = 0;       // iterations of the dense phase (0 = default)
 };
 
 struct Params {
@@ -73,17 +98,16 @@ struct Params {
 };
 
 // launchers (cuberille_kernels.hip); all asynchronous on `s`
-hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, int z0, int z1, hipStream_t s);
-hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s);
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
-hipError_t launch_heads(const Workspace &w, size_t nwords, u64 totV, u64 totQ, hipStream_t s);
-hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s);
-hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s);
-hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s);
+hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, int z0, int z1, const Tuning &t,
+                           hipStream_t s);
+hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s);
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, hipStream_t s);
+hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, hipStream_t s);
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
+                              const Tuning &t, hipStream_t s);
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ, hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
-                          const Params &p, u64 nPoints, u64 nGhost, hipStream_t s);
-size_t scan_temp_bytes(size_t nseg);
-hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, size_t n, hipStream_t s);
+                          const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, hipStream_t s);
 
 }  // namespace cuberille
 #endif

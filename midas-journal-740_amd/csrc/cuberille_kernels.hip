@@ -7,31 +7,29 @@
 // Design (DESIGN.md sections 4-5): the order-dependent raster sweep with its two std::map lookups
 // is replaced by a closed form over a packed inside-bit volume:
 //   classify : one coalesced, nontemporal pass over the voxels, 16 B per lane, thresholds against the
-//              iso value and packs 64 voxels per uint64 word (cross-lane OR)      -> bits
+//              iso value and packs 64 voxels per uint64 word (DPP OR inside the lane group); the words of a
+//              1 MiB span are staged in LDS and leave as 16-byte write-through stores          -> bits
 //   count    : per block of 2048 words: face masks for every word, then one lane per word that has a
-//              face: SWAR boolean algebra over the 27 neighbour bit-rows gives the 8 "this voxel
-//              creates corner i" masks; popcounts + a wavefront scan per 64-word segment
-//                                                                                -> prefix, seg totals
-//   scan     : hipCUB exclusive sum over the per-segment totals                  -> segBase
+//              face: 3-input boolean algebra (v_bitop3) over the 27 neighbour bit-rows gives the 8 "this
+//              voxel creates corner i" masks; popcounts + a wavefront scan per 64-word segment + a scan
+//              over the block's 32 segments; block totals are published with agent-scope atomics and the
+//              LAST block to arrive scans them (no separate scan launches)       -> prefix, segPre, blockBase
 //   emit     : points: one lane per vertex-creating word writes descriptors into LDS, then one lane per
 //              vertex; cells: one lane per output quad, located by a per-wave search of the prefix
 //              arrays, ids staged through LDS; everything lands at its final, reference-order index;
 //              corner ids through a dense lattice-corner map
-//   project  : refilling waves, the damped gradient walk with the gradient image evaluated on the
-//              fly (never materialised); runs between the point and the cell pass so that the
-//              shorter-diagonal triangle split is fused into the cell pass.
+//   project  : phase A, one lane per vertex, walks while the vertex stays in its start cell (dense waves,
+//              one gather); phase B, refilling waves, carries the survivors on; the gradient image is
+//              evaluated on the fly (never materialised); runs between the point and the cell pass so that
+//              the shorter-diagonal triangle split is fused into the cell pass.
 // Bit-exactness of the floating-point part against the CPU oracle relies on
-// -ffp-contract=off (no FMA fusion; the explicit fma calls in k_project are the compiler's own f64
+// -ffp-contract=off (no FMA fusion; the explicit fma calls in the walk are the compiler's own f64
 // sqrt / division sequences written out) and IEEE f64 arithmetic; see csrc/Makefile.
-// Tuning switches read from the environment (defaults are the measured best): CUBERILLE_PROJ_CHUNK,
-// CUBERILLE_PROJ_WAVES, CUBERILLE_PROJ_REFILL, CUBERILLE_PROJ_XCD, CUBERILLE_PROJ_LITERAL,
-// CUBERILLE_CLASSIFY_VARIANT, CUBERILLE_CLASSIFY_GRID, CUBERILLE_POINTS_VARIANT, CUBERILLE_HEADS_SWEEP,
-// CUBERILLE_NO_STREAM_CLASSIFY (and the test switches CUBERILLE_NO_CMAP / NO_HEADS / NO_VQUEUE in the host layer).
+// Development switches live in cuberille::Tuning (cuberille_debug_set_option), not in the environment.
 
 #include "cuberille_internal.h"
 #include "../../include/cuberille_hip.h"
 
-#include <hipcub/hipcub.hpp>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -98,7 +96,7 @@ __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
 template <class T, int U, bool NT>
 __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox, u64 *__restrict__ bits,
                                                        u64 nchunks, double isoD, u32 *__restrict__ sliceOcc,
-                                                       int lgWordsPerSlice) {
+                                                       int lgWordsPerSlice, u64 wordBase) {
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
   const T iso = (T)isoD;
@@ -131,9 +129,85 @@ __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox
         const u64 widx = (c + u) * VPL + lane / LPW;
         bits[widx] = part;
         // slice occupancy on the fly when a slice is 2^n words (else k_occupancy derives it afterwards)
-        if (lgWordsPerSlice >= 0 && part) sliceOcc[widx >> lgWordsPerSlice] = 1u;   // benign race: all store 1
+        if (lgWordsPerSlice >= 0 && part) sliceOcc[(wordBase + widx) >> lgWordsPerSlice] = 1u;   // benign race: all store 1
       }
     }
+  }
+}
+
+// OR over each group of LPW consecutive lanes on the DPP data path (row_shr steps inside the 16-lane rows, row_bcast
+// across them; no LDS round trips); the result is valid in the group's LAST lane.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u64 or_dpp64(u64 v) {
+  const u32 lo = (u32)v, hi = (u32)(v >> 32);
+  const u32 lo2 = lo | (u32)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROWMASK, 0xf, false);
+  const u32 hi2 = hi | (u32)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROWMASK, 0xf, false);
+  return (u64)lo2 | ((u64)hi2 << 32);
+}
+template <int LPW>
+__device__ __forceinline__ u64 group_or(u64 part) {
+  if (LPW >= 2) part = or_dpp64<0x111, 0xf>(part);     // row_shr:1
+  if (LPW >= 4) part = or_dpp64<0x112, 0xf>(part);     // row_shr:2
+  if (LPW >= 8) part = or_dpp64<0x114, 0xf>(part);     // row_shr:4
+  if (LPW >= 16) part = or_dpp64<0x118, 0xf>(part);    // row_shr:8
+  if (LPW >= 32) part = or_dpp64<0x142, 0xa>(part);    // row_bcast:15 into rows 1 and 3
+  return part;
+}
+
+// Large volumes: the sweep is bound by HBM reads (6.7-7.1 TB/s for a kernel that only reads), and what costs it is
+// the 1-bit-per-voxel WRITE stream trickling out of L2 between the reads (measured, profiles/microbench: 0.78 ms
+// with write-back 32-byte stores, 0.63 ms with the stores removed).  Here a block owns whole spans of SPAN_WORDS
+// words: its four waves threshold 8 KiB trips in turn into an LDS stage, then the 32 KiB of words leave as 16-byte
+// write-through (sc1) stores in one burst: 0.71-0.72 ms.
+constexpr int SPAN_WORDS = 4096;
+
+template <class T>
+__global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
+                                                       double isoD, u32 *__restrict__ sliceOcc, int lgWordsPerSlice) {
+  constexpr int U = 8;
+  constexpr int VPL = 16 / sizeof(T);
+  constexpr int LPW = 64 / VPL;
+  constexpr int TRIPS = SPAN_WORDS / (4 * U * VPL);      // trips of U KiB per wave and span
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) u64 stage[SPAN_WORDS];
+  const T iso = (T)isoD;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane % LPW;
+  const bool last = sub == LPW - 1;
+  for (u64 sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
+    const u64 c0 = sp * (u64)(4 * TRIPS * U);            // first 1 KiB chunk of the span
+#pragma unroll 1
+    for (int i = 0; i < TRIPS; i++) {
+      const int tl = i * 4 + wib;                        // the waves take the span's trips in turn
+      Vec16<T> r[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(vox + ((c0 + (u64)tl * U + u) * 64 + lane) * VPL);
+        r[u].raw.x = __builtin_nontemporal_load(&src->x); r[u].raw.y = __builtin_nontemporal_load(&src->y);
+        r[u].raw.z = __builtin_nontemporal_load(&src->z); r[u].raw.w = __builtin_nontemporal_load(&src->w);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const u32 m = inside_bits<T>(r[u], iso);
+        const u64 word = group_or<LPW>((u64)m << (sub * VPL));
+        if (last) stage[(tl * U + u) * VPL + lane / LPW] = word;
+      }
+    }
+    __syncthreads();
+    const u64 w0 = sp * (u64)SPAN_WORDS;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(bits + w0, 0, SPAN_WORDS * 8, 0x00020000);
+    for (int i = threadIdx.x * 2; i < SPAN_WORDS; i += 512) {
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(&stage[i]);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, i * 8, 0, 16);          // aux 16 = sc1: write-through
+      if (lgWordsPerSlice > 0) {
+        if (v.x | v.y | v.z | v.w) sliceOcc[(w0 + i) >> lgWordsPerSlice] = 1u;  // both words lie in one slice
+      } else if (lgWordsPerSlice == 0) {
+        if (v.x | v.y) sliceOcc[w0 + i] = 1u;
+        if (v.z | v.w) sliceOcc[w0 + i + 1] = 1u;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -199,7 +273,10 @@ __global__ __launch_bounds__(256) void k_classify_rows(const T *__restrict__ vox
     bool in = false;
     if (x < nx) in = !(vox[row * (u64)nx + x] < iso);
     const u64 word = __ballot(in);
-    if (lane == 0) bits[t] = word;
+    if (lane == 0) {
+      bits[t] = word;
+      if (word) sliceOcc[row / rowsPerSlice] = 1u;
+    }
   }
 }
 
@@ -225,25 +302,21 @@ __global__ __launch_bounds__(256) void k_occupancy(const u64 *__restrict__ bits,
   if (threadIdx.x == 0) sliceOcc[blockIdx.x] = found ? 1u : 0u;
 }
 
-// Empty-slice aliasing table (reference quirk Q1, txx:139-141 precede 156-161: the lookup
-// planes are swapped only when an INSIDE voxel is met at a new z).  alias[z] = zp when
-// slice z is occupied, slice z-1 is not, and zp < z-1 is the previous occupied slice:
-// bottom-plane corners of slice z are then looked up among the top-plane corners of zp.
-__global__ void k_alias(const u32 *__restrict__ sliceOcc, int *__restrict__ alias, Grid g, int q1,
-                        Totals *__restrict__ tot) {
-  const int z = blockIdx.x * blockDim.x + threadIdx.x;
-  if (z >= g.nzb) return;
-  int a = -1;
-  // (a slab cannot see occupied slices below its buffer: the multi-GPU driver checks the gathered
-  //  per-slice occupancy for that case)
-  if (q1 && z > 0 && sliceOcc[z] && !sliceOcc[z - 1]) {
-    int p = z - 2;
-    while (p >= 0 && !sliceOcc[p]) p--;
-    a = p;
-  }
-  // the aliased source rows must lie inside the counted range to have ids
-  if (a >= 0 && a < g.cz0 && z >= g.cz0) { atomicOr(&tot->err, (u32)ERRF_ALIAS_UNKNOWN); a = -1; }
-  alias[z] = a;
+// Empty-slice aliasing (reference quirk Q1, txx:139-141 precede 156-161: the lookup planes are swapped only when
+// an INSIDE voxel is met at a new z).  For a slice z that holds an inside voxel (every caller's does): when slice
+// z-1 holds none and zp < z-1 is the previous occupied slice, bottom-plane corners of slice z are looked up among
+// the top-plane corners of zp.  Returns zp or -1.  The usual answer costs one cached load.
+// unknown (an ERRF_* bit, raised by the count kernel): the source lies in the buffer but below the counted range
+// [cz0, ..) -- its ids belong to the rank below -- or the search fell off the bottom of a slab buffer that does not
+// start at the volume's first slice (the multi-GPU driver knows whether anything is occupied down there).
+__device__ __forceinline__ int alias_of(const u32 *__restrict__ occ, const Grid &g, int q1, int z, u32 &unknown) {
+  unknown = 0;
+  if (!q1 || z <= 0 || occ[z - 1]) return -1;
+  int p = z - 2;
+  while (p >= 0 && !occ[p]) p--;
+  if (p >= 0 && p < g.cz0 && z >= g.cz0) { unknown = ERRF_ALIAS_UNKNOWN; return -1; }
+  if (p < 0 && g.zglob0 > 0) unknown = ERRF_ALIAS_BELOW_BUFFER;
+  return p;
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP data path (no LDS round trips, unlike __shfl_up):
@@ -261,20 +334,16 @@ __device__ __forceinline__ u32 wave_inclusive_sum(u32 v) {
 // ---------------------------------------------------------------------------------------------
 // Word classification: everything a 64-voxel word needs, from the 27 neighbour bit-rows.
 // ---------------------------------------------------------------------------------------------
-struct Rows3 { u64 m, c, p; };   // bit x = inside(x-1), inside(x), inside(x+1), border-clamped (I2)
-
-__device__ __forceinline__ Rows3 load_row(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k) {
-  // three unconditional loads (the neighbour indices are clamped, the selects are ALU): all 27 loads
-  // of a neighbourhood are independent and issue back to back, one memory latency in total
-  const u64 *r = bits + ((size_t)z * g.ny + y) * g.W;
-  const int kp = k > 0 ? k - 1 : 0, kn = k < g.W - 1 ? k + 1 : k;
-  const u64 c = r[k], wp = r[kp], wn = r[kn];
-  Rows3 o;
-  o.c = c;
-  o.m = (c << 1) | (k > 0 ? (wp >> 63) : (c & 1ull));
-  o.p = (c >> 1) | (k < g.W - 1 ? (wn << 63) : (c & (1ull << g.lastpos)));
-  return o;
+// 3-input boolean function of 64-bit operands on the gfx950 v_bitop3_b32 (truth table TT: bit (a<<2 | b<<1 | c))
+template <int TT>
+__device__ __forceinline__ u64 bop3(u64 a, u64 b, u64 c) {
+  const u32 lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, TT);
+  const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), TT);
+  return (u64)lo | ((u64)hi << 32);
 }
+constexpr int TT_AND3 = 0x80, TT_OR3 = 0xfe, TT_A_ANDN_B = 0x30;   // a&b&c, a|b|c, a&~b
+
+struct Rows3 { u64 m, c, p; };   // bit x = inside(x-1), inside(x), inside(x+1), border-clamped (I2)
 
 __device__ __forceinline__ u64 valid_mask(const Grid &g, int k) {
   return (k == g.W - 1 && g.lastpos != 63) ? ((2ull << g.lastpos) - 1ull) : ~0ull;
@@ -303,6 +372,39 @@ __device__ __forceinline__ void word_coords(const Grid &g, size_t gi, int &k, in
   }
 }
 
+// A word inside the bit volume and the (clamped) word offsets of its neighbours: the neighbour rows are the word's
+// own address plus an offset that is 0 at the image border (ZeroFluxNeumann: the clamped neighbour is the row itself).
+struct WordPos {
+  const u64 *q;                 // &bits[(z*ny + y)*W + k]
+  int k, y, z;
+  long long km, kp;             // -1 / +1, or 0 at the row ends
+  long long yo[3], zo[3];       // word offsets of rows y-1, y, y+1 and slices z-1, z, z+1 (clamped)
+};
+
+__device__ __forceinline__ WordPos word_pos(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k) {
+  WordPos w;
+  w.q = bits + ((size_t)z * g.ny + y) * g.W + k;
+  w.k = k; w.y = y; w.z = z;
+  w.km = k > 0 ? -1 : 0;
+  w.kp = k < g.W - 1 ? 1 : 0;
+  const long long rs = g.W, ss = (long long)g.W * g.ny;
+  w.yo[0] = y > 0 ? -rs : 0;          w.yo[1] = 0;  w.yo[2] = y < g.ny - 1 ? rs : 0;
+  w.zo[0] = z > 0 ? -ss : 0;          w.zo[1] = 0;  w.zo[2] = z < g.nzb - 1 ? ss : 0;
+  return w;
+}
+
+// the row at word offset `off` from the word: three unconditional loads (all loads of a neighbourhood are
+// independent and issue back to back, one memory latency in total), the selects are ALU
+__device__ __forceinline__ Rows3 load_row(const WordPos &w, const Grid &g, long long off) {
+  const u64 *r = w.q + off;
+  const u64 c = r[0], wp = r[w.km], wn = r[w.kp];
+  Rows3 o;
+  o.c = c;
+  o.m = (c << 1) | (w.k > 0 ? (wp >> 63) : (c & 1ull));
+  o.p = (c >> 1) | (w.k < g.W - 1 ? (wn << 63) : (c & (1ull << g.lastpos)));
+  return o;
+}
+
 struct WordInfo {
   u64 F[6];   // F[f] bit x: voxel x emits a quad on face f                  (txx:164-173)
   u64 C[8];   // C[i] bit x: voxel x is the first to need its corner i, i.e. the reference
@@ -310,65 +412,74 @@ struct WordInfo {
 };
 
 struct Neigh {
-  Rows3 v[3][3];     // [dz+1][dy+1]
-  u64 exX[3];        // voxel x+dx exists (dx = -1,0,+1)
-  u64 exY[3], exZ[3];
+  u64 raw[3][3][3];  // [dz+1][dy+1][dx+1] bit x: inside(x+dx, y+dy, z+dz), every coordinate clamped into the image
+  u64 e[3][3][3];    // the same AND "that voxel exists" (off the image: 0)
 };
 
-template <int SX>
-__device__ __forceinline__ u64 selx(const Rows3 &r) { return SX < 0 ? r.m : (SX == 0 ? r.c : r.p); }
-
-// inside-bit of block member e (code x|y<<1|z<<2) of the 2x2x2 block around corner D of voxel x
-template <int D, int E>
-__device__ __forceinline__ u64 blk(const Neigh &n) {
-  constexpr int sx = (D & 1) - (E & 1), sy = ((D >> 1) & 1) - ((E >> 1) & 1), sz = (D >> 2) - (E >> 2);
-  return selx<sx>(n.v[sz + 1][sy + 1]);
-}
-// block member e activates the corner: it exists, is inside, and at least one of its three
-// face neighbours inside the block is outside
+// block member E (code x|y<<1|z<<2) of the 2x2x2 block around corner D of voxel x sits at offset D - E per axis.
+// It activates the corner when it exists, is inside, and at least one of its three face neighbours inside the
+// block is outside: two 3-input operations per 32-bit half.
 template <int D, int E>
 __device__ __forceinline__ u64 act(const Neigh &n) {
   constexpr int sx = (D & 1) - (E & 1), sy = ((D >> 1) & 1) - ((E >> 1) & 1), sz = (D >> 2) - (E >> 2);
-  const u64 ex = n.exX[sx + 1] & n.exY[sy + 1] & n.exZ[sz + 1];
-  return ex & blk<D, E>(n) & ~(blk<D, E ^ 1>(n) & blk<D, E ^ 2>(n) & blk<D, E ^ 4>(n));
+  constexpr int nx_ = (D & 1) - ((E ^ 1) & 1), ny_ = ((D >> 1) & 1) - (((E ^ 2) >> 1) & 1), nz_ = (D >> 2) - ((E ^ 4) >> 2);
+  const u64 t = bop3<TT_AND3>(n.raw[sz + 1][sy + 1][nx_ + 1], n.raw[sz + 1][ny_ + 1][sx + 1], n.raw[nz_ + 1][sy + 1][sx + 1]);
+  return bop3<TT_A_ANDN_B>(n.e[sz + 1][sy + 1][sx + 1], t, t);
 }
-template <int D, int... Es>
-__device__ __forceinline__ u64 act_any_later(const Neigh &n, std::integer_sequence<int, Es...>) {
-  // members with code > D come earlier in raster order (they have smaller coordinates)
-  return (0ull | ... | act<D, D + 1 + Es>(n));
+// OR of act<D,E'> over E' = E..7 (members with a larger code come earlier in raster order: smaller coordinates)
+template <int D, int E>
+__device__ __forceinline__ u64 act_from(const Neigh &n) {
+  if constexpr (E > 7) return 0ull;
+  else if constexpr (E == 7) return act<D, 7>(n);
+  else if constexpr (E == 6) return act<D, 6>(n) | act<D, 7>(n);
+  else return bop3<TT_OR3>(act<D, E>(n), act<D, E + 1>(n), act_from<D, E + 2>(n));
 }
 template <int I>
 __device__ __forceinline__ u64 created(const Neigh &n) {
   constexpr int D = (I == 2) ? 3 : (I == 3) ? 2 : (I == 6) ? 7 : (I == 7) ? 6 : I;
-  return act<D, D>(n) & ~act_any_later<D>(n, std::make_integer_sequence<int, 7 - D>());
+  if constexpr (D == 7) return act<7, 7>(n);
+  else return bop3<TT_A_ANDN_B>(act<D, D>(n), act_from<D, D + 1>(n), 0ull);
 }
 
-__device__ __forceinline__ void load_neigh(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, Neigh &n) {
+// YZ: some lane of the wave sits on a y or z border of the buffer (then rows off the image must not activate
+// anything); interior waves skip those masks.  The x ends cost one mask on the shifted rows either way.
+template <bool YZ>
+__device__ __forceinline__ void load_neigh(const WordPos &w, const Grid &g, Neigh &n) {
+  const u64 valid = valid_mask(g, w.k);
+  const u64 exm = (w.k == 0) ? ~1ull : ~0ull;
+  const u64 exp_ = (w.k == g.W - 1) ? (valid >> 1) : ~0ull;
 #pragma unroll
-  for (int dz = -1; dz <= 1; dz++)
+  for (int dz = 0; dz < 3; dz++)
 #pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
-      n.v[dz + 1][dy + 1] = load_row(bits, g, clampi(y + dy, 0, g.ny - 1), clampi(z + dz, 0, g.nzb - 1), k);
-  const u64 valid = valid_mask(g, k);
-  n.exX[0] = (k == 0) ? ~1ull : ~0ull;
-  n.exX[1] = valid;
-  n.exX[2] = (k == g.W - 1) ? (valid >> 1) : ~0ull;
-  n.exY[0] = (y > 0) ? ~0ull : 0ull;  n.exY[1] = ~0ull;  n.exY[2] = (y < g.ny - 1) ? ~0ull : 0ull;
-  n.exZ[0] = (z > 0) ? ~0ull : 0ull;  n.exZ[1] = ~0ull;  n.exZ[2] = (z < g.nzb - 1) ? ~0ull : 0ull;
+    for (int dy = 0; dy < 3; dy++) {
+      const Rows3 r = load_row(w, g, w.yo[dy] + w.zo[dz]);
+      n.raw[dz][dy][0] = r.m; n.raw[dz][dy][1] = r.c; n.raw[dz][dy][2] = r.p;
+      u64 rowex = ~0ull;
+      if (YZ) {
+        const bool ex = (dy == 1 || (dy == 0 ? w.y > 0 : w.y < g.ny - 1)) && (dz == 1 || (dz == 0 ? w.z > 0 : w.z < g.nzb - 1));
+        rowex = ex ? ~0ull : 0ull;
+      }
+      n.e[dz][dy][0] = r.m & exm & rowex;
+      n.e[dz][dy][1] = r.c & rowex;
+      n.e[dz][dy][2] = r.p & exp_ & rowex;
+    }
 }
 
 // AE[i] (i = 0..3) bit x: bottom corner i of voxel x already exists as a top-plane corner of the
 // aliased source slice zp (any existing inside voxel of slice zp touching that (x,y) corner).
-__device__ __forceinline__ void alias_exists(const u64 *__restrict__ bits, const Grid &g, const Neigh &n,
-                                             int y, int zp, int k, u64 AE[4]) {
+__device__ __forceinline__ void alias_exists(const WordPos &w, const Grid &g, int zp, u64 AE[4]) {
+  const u64 valid = valid_mask(g, w.k);
+  const u64 exX[3] = {(w.k == 0) ? ~1ull : ~0ull, valid, (w.k == g.W - 1) ? (valid >> 1) : ~0ull};
+  const u64 exY[3] = {(w.y > 0) ? ~0ull : 0ull, ~0ull, (w.y < g.ny - 1) ? ~0ull : 0ull};
+  const long long toZp = (long long)(zp - w.z) * g.W * g.ny;
   Rows3 r[3];
 #pragma unroll
-  for (int dy = -1; dy <= 1; dy++) r[dy + 1] = load_row(bits, g, clampi(y + dy, 0, g.ny - 1), zp, k);
+  for (int dy = 0; dy < 3; dy++) r[dy] = load_row(w, g, toZp + w.yo[dy]);
   // corner offsets (dx,dy) of corners 0..3: (0,0) (1,0) (1,1) (0,1); voxels (x+dx-ex, y+dy-ey)
   auto at = [&](int sx, int sy) -> u64 {
     const Rows3 &rr = r[sy + 1];
     const u64 b = sx < 0 ? rr.m : (sx == 0 ? rr.c : rr.p);
-    return b & n.exX[sx + 1] & n.exY[sy + 1];
+    return b & exX[sx + 1] & exY[sy + 1];
   };
   AE[0] = at(0, 0) | at(-1, 0) | at(0, -1) | at(-1, -1);
   AE[1] = at(1, 0) | at(0, 0) | at(1, -1) | at(0, -1);
@@ -376,53 +487,76 @@ __device__ __forceinline__ void alias_exists(const u64 *__restrict__ bits, const
   AE[3] = at(0, 1) | at(-1, 1) | at(0, 0) | at(-1, 0);
 }
 
-__device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, const int *__restrict__ alias,
-                                              const Grid &g, int y, int z, int k, WordInfo &w) {
+// The eight "voxel x creates its corner i" masks of one word (and, FACES, its six face masks).
+// `unknown`: ERRF_* bits of alias_of for the count kernel to raise; the other callers ignore them.
+template <bool FACES>
+__device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, const u32 *__restrict__ occ, const Grid &g, int q1,
+                                              int y, int z, int k, WordInfo &w, u32 &unknown) {
+  const bool yzBorder = y == 0 || y == g.ny - 1 || z == 0 || z == g.nzb - 1;
+  const bool anyBorder = __ballot(yzBorder) != 0ull;      // uniform over the lanes that are here
+  const WordPos wp = word_pos(bits, g, y, z, k);
   Neigh n;
-  load_neigh(bits, g, y, z, k, n);
-  const u64 I = n.v[1][1].c;
-  w.F[0] = I & ~n.v[1][1].m;   // -x   (offsets of txx:122-127)
-  w.F[1] = I & ~n.v[1][0].c;   // -y
-  w.F[2] = I & ~n.v[1][1].p;   // +x
-  w.F[3] = I & ~n.v[1][2].c;   // +y
-  w.F[4] = I & ~n.v[0][1].c;   // -z
-  w.F[5] = I & ~n.v[2][1].c;   // +z
+  if (anyBorder) load_neigh<true>(wp, g, n); else load_neigh<false>(wp, g, n);
+  if (FACES) {
+    const u64 I = n.raw[1][1][1];
+    w.F[0] = I & ~n.raw[1][1][0];   // -x   (offsets of txx:122-127)
+    w.F[1] = I & ~n.raw[1][0][1];   // -y
+    w.F[2] = I & ~n.raw[1][1][2];   // +x
+    w.F[3] = I & ~n.raw[1][2][1];   // +y
+    w.F[4] = I & ~n.raw[0][1][1];   // -z
+    w.F[5] = I & ~n.raw[2][1][1];   // +z
+  }
   w.C[0] = created<0>(n); w.C[1] = created<1>(n); w.C[2] = created<2>(n); w.C[3] = created<3>(n);
   w.C[4] = created<4>(n); w.C[5] = created<5>(n); w.C[6] = created<6>(n); w.C[7] = created<7>(n);
-  const int zp = alias[z];
+  const int zp = alias_of(occ, g, q1, z, unknown);
   if (zp >= 0) {
     u64 AE[4];
-    alias_exists(bits, g, n, y, zp, k, AE);
+    alias_exists(wp, g, zp, AE);
 #pragma unroll
     for (int i = 0; i < 4; i++) w.C[i] &= ~AE[i];
   }
 }
 
-__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]);
+// the six face masks of a word only (7 bit-rows instead of 27)
+__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
+  const WordPos w = word_pos(bits, g, y, z, k);
+  const Rows3 c = load_row(w, g, 0);
+  const u64 ym = w.q[w.yo[0]], yp = w.q[w.yo[2]], zm = w.q[w.zo[0]], zp = w.q[w.zo[2]];
+  F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
+}
 
 // ---------------------------------------------------------------------------------------------
-// K2: count.  A block owns COUNT_WB consecutive words of the flat raster order (32 scan segments).
+// K2: count + scan.  A block owns COUNT_WB consecutive words of the flat raster order (32 scan segments).
 //   phase 1  every word: the six face masks (7 bit-rows) -> quad count; words with a face are
 //            queued in LDS (a voxel only creates corners on faces it emits, so words without a
 //            face create nothing)
-//   phase 2  one lane per QUEUED word: the 8 created-corner masks (27 bit-rows, ~600 ALU ops) ->
-//            vertex count.  The surface touches a fraction of the words, so the expensive part
-//            runs on densely packed lanes instead of on every word.
-//   phase 3  one wave per segment: exclusive scan of the packed counts -> prefix, segment totals.
+//   phase 2  one lane per QUEUED word: the 8 created-corner masks (27 bit-rows) -> vertex count.  The surface
+//            touches a fraction of the words, so the expensive part runs on densely packed lanes.
+//   phase 3  one wave per segment: exclusive scan of the packed counts -> prefix; then the block's 32 segment
+//            totals are scanned -> segPre, and the block total is PUBLISHED: one agent-scope atomic exchange
+//            of V | Q<<32 into blockTot[b], then one atomic add on a ticket.
+//   phase 4  the block whose ticket is the last one reads all block totals back (agent-scope atomic loads:
+//            the exchanges and these loads meet at the memory side, no cache holds those lines), scans them and
+//            writes blockBase and the grand totals.  No look-back spinning: nobody ever waits for another block.
 // ---------------------------------------------------------------------------------------------
-constexpr int COUNT_WB = 2048;
+__device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independent 32-bit sums packed lo | hi<<32
+  return (u64)wave_inclusive_sum((u32)v) | ((u64)wave_inclusive_sum((u32)(v >> 32)) << 32);
+}
 
-__global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const int *__restrict__ alias, Grid g,
-                                               size_t nwords, u32 *__restrict__ prefix, u64 *__restrict__ segV,
-                                               u64 *__restrict__ segQ, u32 *__restrict__ vqueue,
-                                               Totals *__restrict__ tot) {
+__global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
+                                               size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
+                                               u64 *__restrict__ blockTot, u64 *__restrict__ blockBase,
+                                               u32 *__restrict__ vqueue, Totals *__restrict__ tot) {
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
   __shared__ unsigned short queue[COUNT_WB], vlist[COUNT_WB];
+  __shared__ u64 segTot[COUNT_WB / 64];
+  __shared__ u64 lastSum[256];
   __shared__ int nQueued, nVertexWords;
-  __shared__ u32 vbase;
+  __shared__ u32 vbase, g0InSeg, amLast;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
-  if (tid == 0) { nQueued = 0; nVertexWords = 0; }
+  const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
+  if (tid == 0) { nQueued = 0; nVertexWords = 0; g0InSeg = 0; amLast = 0; }
   __syncthreads();
   for (int i = tid; i < COUNT_WB; i += 256) {
     const size_t gi = w0 + i;
@@ -446,13 +580,16 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
   }
   __syncthreads();
   const int nq = nQueued;
+  u32 errBits = 0;
   for (int j = tid; j < nq; j += 256) {
     const int i = queue[j];
     const size_t gi = w0 + i;
     int k, y, z;
     word_coords(g, gi, k, y, z);
     WordInfo w;
-    classify_word(bits, alias, g, y, z, k, w);
+    u32 unknown;
+    classify_word<false>(bits, occ, g, q1, y, z, k, w, unknown);
+    errBits |= unknown;
     int nV = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
@@ -461,6 +598,7 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     // such word)
     if (nV && vqueue) vlist[atomicAdd(&nVertexWords, 1)] = (unsigned short)i;
   }
+  if (errBits) atomicOr(&tot->err, errBits);
   __syncthreads();
   if (vqueue) {
     const int nvw = nVertexWords;
@@ -470,31 +608,82 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
   }
   for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
     const size_t gi = w0 + sg * 64 + lane;
-    if ((gi & ~(size_t)63) >= nwords) break;    // wave-uniform
     const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
     const u32 incl = wave_inclusive_sum(packed);
     if (gi < nwords) prefix[gi] = incl - packed;
-    if (lane == 63) {
-      segV[gi >> 6] = incl & 0xffffu;
-      segQ[gi >> 6] = incl >> 16;
+    if (gi == g0) g0InSeg = incl - packed;
+    if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
+  }
+  __syncthreads();
+  if (wv == 0) {
+    // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot, ticket
+    const u64 t = lane < COUNT_WB / 64 ? segTot[lane] : 0ull;
+    const u64 incl = wave_inclusive_sum2(t);
+    const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
+    const size_t seg = (w0 >> 6) + lane;
+    if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
+    if (g0 > 0 && (g0 >> COUNT_LG) == blockIdx.x && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
+      const u32 in = g0InSeg;
+      const u64 was = __hip_atomic_exchange(&tot->g0pre, excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32)),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"((u32)was));                          // a returning atomic: its completion is waited for
+    }
+    if (lane == COUNT_WB / 64 - 1) {
+      const u64 was = __hip_atomic_exchange(&blockTot[blockIdx.x], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"((u32)was));
+    }
+    // the exchanges above have returned (their results are waited for) before any lane of this wave adds to the
+    // ticket: whoever sees the last ticket sees every block total
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const u32 old = __hip_atomic_fetch_add(&tot->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      amLast = (old == gridDim.x - 1) ? 1u : 0u;
     }
   }
-}
-
-__global__ void k_finalize(const u32 *__restrict__ prefix, const u64 *__restrict__ segV, const u64 *__restrict__ segQ,
-                           const u64 *__restrict__ segBaseV, const u64 *__restrict__ segBaseQ, Grid g, size_t nwords,
-                           Totals *__restrict__ tot) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const size_t nseg = (nwords + 63) >> 6;
-  tot->totV = segBaseV[nseg - 1] + segV[nseg - 1];
-  tot->totQ = segBaseQ[nseg - 1] + segQ[nseg - 1];
-  const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
-  if (g0 > 0) {
-    tot->V0 = segBaseV[g0 >> 6] + (prefix[g0] & 0xffffu);
-    tot->Q0 = segBaseQ[g0 >> 6] + (prefix[g0] >> 16);
-  } else {
-    tot->V0 = 0;
-    tot->Q0 = 0;
+  __syncthreads();
+  if (!amLast) return;
+  // ---- the last block: scan of the block totals ----------------------------------------------------------------
+  const u32 nblk = gridDim.x;
+  const u32 per = (nblk + 255) / 256;
+  const u32 b0 = tid * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  u64 sumV = 0, sumQ = 0;
+  for (u32 b = b0; b < b1; b++) {
+    const u64 t = __hip_atomic_load(&blockTot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sumV += t & 0xffffffffull;
+    sumQ += t >> 32;
+  }
+  // exclusive scan of the 256 partial sums (u64 each; V and Q separately through LDS)
+  u64 baseV, baseQ;
+  {
+    lastSum[tid] = sumV;
+    __syncthreads();
+    u64 acc = 0;
+    for (int i = 0; i < tid; i++) acc += lastSum[i];
+    baseV = acc;
+    u64 all = acc;
+    for (int i = tid; i < 256; i++) all += lastSum[i];
+    __syncthreads();
+    if (tid == 0) tot->totV = all;
+    lastSum[tid] = sumQ;
+    __syncthreads();
+    acc = 0;
+    for (int i = 0; i < tid; i++) acc += lastSum[i];
+    baseQ = acc;
+    all = acc;
+    for (int i = tid; i < 256; i++) all += lastSum[i];
+    if (tid == 0) tot->totQ = all;
+  }
+  for (u32 b = b0; b < b1; b++) {
+    const u64 t = __hip_atomic_load(&blockTot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    blockBase[2 * (size_t)b] = baseV;
+    blockBase[2 * (size_t)b + 1] = baseQ;
+    if (g0 > 0 && (g0 >> COUNT_LG) == b) {
+      const u64 in = __hip_atomic_load(&tot->g0pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot->V0 = baseV + (in & 0xffffffffull);
+      tot->Q0 = baseQ + (in >> 32);
+    }
+    baseV += t & 0xffffffffull;
+    baseQ += t >> 32;
   }
 }
 
@@ -503,9 +692,12 @@ __global__ void k_finalize(const u32 *__restrict__ prefix, const u64 *__restrict
 // ---------------------------------------------------------------------------------------------
 struct EmitArgs {
   const u64 *bits;
-  const int *alias;
-  const u32 *prefix;
-  const u64 *segBaseV, *segBaseQ;
+  const u32 *occ;      // per-slice occupancy (quirk Q1)
+  int q1;
+  const u32 *prefix;   // the three levels of the prefix sums: word in segment, segment in block, block
+  const u64 *segPre;
+  const u64 *blockBase;
+  size_t nblk;
   const Totals *tot;
   float *points;
   u64 *cells;          // 4 ids per quad, or 2 x 3 ids per quad when triangulating
@@ -513,6 +705,13 @@ struct EmitArgs {
   u32 *cmap;           // dense lattice-corner -> vertex index map, or null (see corner_map_index)
   const u32 *headV, *headQ;   // word producing output 64*i (k_heads), or null
 };
+
+// absolute exclusive prefix (SHIFT 0: vertices, 16: quads) at the start of the segment that holds word gi
+template <int SHIFT>
+__device__ __forceinline__ u64 seg_base(const EmitArgs &a, size_t gi) {
+  const u64 sp = a.segPre[gi >> 6];
+  return a.blockBase[2 * (gi >> COUNT_LG) + (SHIFT ? 1 : 0)] + (SHIFT ? (sp >> 32) : (sp & 0xffffffffull));
+}
 
 // The reference finds a corner's id in a std::map keyed by (x,y) per z-plane (h:272-313).  With
 // 288 GB of HBM the MI355X equivalent is a dense array over all (nx+1)(ny+1)(nz+1) lattice corners,
@@ -564,9 +763,10 @@ __device__ u64 corner_id_generic(const EmitArgs &a, const Grid &g, int cx, int c
   const int wx = cx - (creator & 1), wy = cy - ((creator >> 1) & 1), wz = cz - (creator >> 2);
   const int k = wx >> 6, bx = wx & 63;
   WordInfo w;
-  classify_word(a.bits, a.alias, g, wy, wz, k, w);
+  u32 unk;
+  classify_word<false>(a.bits, a.occ, g, a.q1, wy, wz, k, w, unk);
   const size_t gi = word_index(g, wy, wz, k);
-  u64 id = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);
+  u64 id = seg_base<0>(a, gi) + (a.prefix[gi] & 0xffffu);
   unsigned cm = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -578,196 +778,67 @@ __device__ u64 corner_id_generic(const EmitArgs &a, const Grid &g, int cx, int c
   return id;
 }
 
-// Inverse mapping: output index -> source.  Every output (vertex, quad) has exactly one producing
-// voxel and its id is its position in the raster-ordered enumeration, so a block that owns a fixed
-// range of 1024 words (16 scan segments) knows the contiguous range of outputs it must write:
-//   1. stage the words' exclusive output prefixes in LDS (block-relative),
-//   2. compact the non-empty words (block scan), classify them once each -- one lane per non-empty
-//      word, 256 per round -- and park their bit masks in LDS,
-//   3. one lane per OUTPUT: binary search in LDS for its word, popcount-select the voxel and the
-//      corner/face inside the word, write.
-// The surface is ~1 % of the voxels: a lane per voxel (or per word) would idle almost every lane,
-// a lane per output keeps them all busy and writes each output buffer front to back.
-constexpr int EMIT_WB = 1024;       // words per block
-constexpr int EMIT_ROUND = 256;     // non-empty words classified per round (one per thread)
-
-struct EmitBlock {
-  u32 pre[EMIT_WB + 1];
-  unsigned short list[EMIT_WB];
-  int waveTot[4];
-};
-
-template <int SHIFT>
-__device__ __forceinline__ int emit_block_setup(EmitBlock &sb, const u64 *__restrict__ segBase,
-                                                const u32 *__restrict__ prefix, u64 total, size_t nwords, size_t w0,
-                                                u64 &base) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  base = segBase[w0 >> 6];
-  const size_t wEnd = (w0 + EMIT_WB < nwords) ? w0 + EMIT_WB : nwords;
-  const u32 tot = (wEnd < nwords) ? (u32)(segBase[wEnd >> 6] - base) : (u32)(total - base);
-  for (int i = tid; i < EMIT_WB; i += 256) {
-    const size_t gi = w0 + i;
-    sb.pre[i] = gi < nwords ? (u32)(segBase[gi >> 6] - base) + ((prefix[gi] >> SHIFT) & 0xffffu) : tot;
-  }
-  if (tid == 0) sb.pre[EMIT_WB] = tot;
-  __syncthreads();
-  bool ne[4];
-  int cnt = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) { ne[j] = sb.pre[tid * 4 + j + 1] > sb.pre[tid * 4 + j]; cnt += ne[j] ? 1 : 0; }
-  int incl = cnt;
-#pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) { const int t = __shfl_up(incl, sft, 64); if (lane >= sft) incl += t; }
-  if (lane == 63) sb.waveTot[wv] = incl;
-  __syncthreads();
-  int off = 0, n = 0;
-#pragma unroll
-  for (int w = 0; w < 4; w++) { if (w < wv) off += sb.waveTot[w]; n += sb.waveTot[w]; }
-  int pos = off + incl - cnt;
-#pragma unroll
-  for (int j = 0; j < 4; j++) if (ne[j]) sb.list[pos++] = (unsigned short)(tid * 4 + j);
-  __syncthreads();
-  return n;
-}
-
-// largest j in [lo, hi) with pre[list[j]] <= o
-__device__ __forceinline__ int emit_find_word(const EmitBlock &sb, int lo, int hi, u32 o) {
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (sb.pre[sb.list[mid]] <= o) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // position of the set bit of rank r (0-based) in an 8-bit mask
 __device__ __forceinline__ int select_bit8(unsigned m, int r) {
   for (int i = 0; i < r; i++) m &= m - 1;
   return __ffs((int)m) - 1;
 }
 
-// K3a: vertices of the counted range (a slab's ghost slice included: the rank above needs those
-// coordinates for the triangle split of its first slice).
-__global__ __launch_bounds__(256) void k_emit_points(EmitArgs a, Grid g, Geo geo, size_t nwords) {
-  __shared__ EmitBlock sb;
-  __shared__ u64 masks[8][EMIT_ROUND];
-  const int tid = threadIdx.x;
-  const size_t w0 = (size_t)blockIdx.x * EMIT_WB;
-  u64 base;
-  const int nList = emit_block_setup<0>(sb, a.segBaseV, a.prefix, a.tot->totV, nwords, w0, base);
-  for (int r0 = 0; r0 < nList; r0 += EMIT_ROUND) {
-    const int rEnd = (r0 + EMIT_ROUND < nList) ? r0 + EMIT_ROUND : nList;
-    if (r0 + tid < rEnd) {
-      const size_t gi = w0 + sb.list[r0 + tid];
-      int k, y, z;
-      word_coords(g, gi, k, y, z);
-      WordInfo w;
-      classify_word(a.bits, a.alias, g, y, z, k, w);
-#pragma unroll
-      for (int i = 0; i < 8; i++) masks[i][tid] = w.C[i];
-    }
-    __syncthreads();
-    const u32 oEnd = sb.pre[sb.list[rEnd - 1] + 1];
-    for (u32 o = sb.pre[sb.list[r0]] + tid; o < oEnd; o += 256) {
-      const int j = emit_find_word(sb, r0, rEnd, o);
-      const int wi = sb.list[j];
-      const u32 r = o - sb.pre[wi];
-      u64 C[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) C[i] = masks[i][j - r0];
-      int lo = 0, hi = 64;                       // largest bit position with (#created before it) <= r
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) c += popc64(C[i] & lowmask(mid));
-        if ((u32)c <= r) lo = mid; else hi = mid;
-      }
-      int before = 0;
-      unsigned cm = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        before += popc64(C[i] & lowmask(lo));
-        cm |= (unsigned)((C[i] >> lo) & 1ull) << i;
-      }
-      const int e = kCornerEnc[select_bit8(cm, (int)r - before)];
-      const size_t gi = w0 + wi;
-      int k, y, z;
-      word_coords(g, gi, k, y, z);
-      const int cx = k * 64 + lo + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
-      const u64 v = base + o;                    // vertex index in the counted range
-      float p[3];
-      corner_point(geo, cx, cy, g.zglob0 + cz, p);
-      float *dst = a.points + 3 * v;             // ghost points first, owned points from 3*V0 on
-      dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-      if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
-    }
-    __syncthreads();
-  }
-}
-
-// Global form of the inverse mapping: one lane per output everywhere (no idle lanes, no block
-// synchronisation).  A wave holds 64 consecutive outputs, which come from a short run of words, so
-// the search is done per wave: `head[o/64]` (built by k_heads after the scan) names the word that
-// produces output o & ~63; the 64 lanes load the absolute prefixes of the 64 words from there on and
-// each lane finds its own word with a 6-step shuffle search -- two dependent memory round trips
-// instead of the 24 of a per-lane binary search over the whole volume.  Outputs that lie beyond the
-// window (sparse surface) slide the window; after a few slides the lane falls back to locate_word.
-__global__ __launch_bounds__(256) void k_heads(const u32 *__restrict__ prefix, const u64 *__restrict__ segV,
-                                               const u64 *__restrict__ segQ, const u64 *__restrict__ segBaseV,
-                                               const u64 *__restrict__ segBaseQ, size_t nwords, u32 *__restrict__ headV,
-                                               u32 *__restrict__ headQ) {
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= nwords) return;
-  const u32 p = prefix[gi];
-  const bool last = ((gi & 63) == 63) || (gi + 1 == nwords);
-  const size_t seg = gi >> 6;
-  const u32 nextV = last ? (u32)segV[seg] : (prefix[gi + 1] & 0xffffu);
-  const u32 nextQ = last ? (u32)segQ[seg] : (prefix[gi + 1] >> 16);
-  const u32 cV = nextV - (p & 0xffffu), cQ = nextQ - (p >> 16);
-  if (cV && headV) {
-    const u64 b = segBaseV[seg] + (p & 0xffffu);
-    for (u64 m = (b + 63) & ~63ull; m < b + cV; m += 64) headV[m >> 6] = (u32)gi;
-  }
-  if (cQ) {
-    const u64 b = segBaseQ[seg] + (p >> 16);
-    for (u64 m = (b + 63) & ~63ull; m < b + cQ; m += 64) headQ[m >> 6] = (u32)gi;
-  }
-}
-
+// Inverse mapping: output index -> source.  Every output (vertex, quad) has exactly one producing voxel and its
+// id is its position in the raster-ordered enumeration.  The surface is ~1 % of the voxels: a lane per voxel (or
+// per word) would idle almost every lane, a lane per OUTPUT keeps them all busy and writes each output buffer
+// front to back.  The word that produces output idx is found through the three levels of the prefix sums: the
+// largest block, then segment, then word whose exclusive prefix is <= idx (entries with equal prefixes are empty,
+// so "the largest" is the one that holds the output).
 template <int SHIFT>
-__device__ __forceinline__ size_t locate_word(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
-                                              size_t nseg, size_t nwords, u64 idx, u32 &within) {
-  size_t lo = 0, hi = nseg;                      // largest seg with segBase[seg] <= idx
+__device__ __forceinline__ size_t locate_word(const EmitArgs &a, size_t nwords, u64 idx, u32 &within) {
+  constexpr int C = SHIFT ? 1 : 0;
+  size_t lo = 0, hi = a.nblk;
   while (hi - lo > 1) {
     const size_t mid = (lo + hi) >> 1;
-    if (segBase[mid] <= idx) lo = mid; else hi = mid;
+    if (a.blockBase[2 * mid + C] <= idx) lo = mid; else hi = mid;
   }
-  const u32 r = (u32)(idx - segBase[lo]);
-  size_t wlo = lo << 6, whi = wlo + 64;
+  u32 r = (u32)(idx - a.blockBase[2 * lo + C]);             // < 2^21
+  const size_t nseg = (nwords + 63) >> 6;
+  size_t slo = lo << (COUNT_LG - 6), shi = slo + (COUNT_WB / 64);
+  if (shi > nseg) shi = nseg;
+  while (shi - slo > 1) {
+    const size_t mid = (slo + shi) >> 1;
+    const u64 sp = a.segPre[mid];
+    if ((u32)(SHIFT ? (sp >> 32) : (sp & 0xffffffffull)) <= r) slo = mid; else shi = mid;
+  }
+  {
+    const u64 sp = a.segPre[slo];
+    r -= (u32)(SHIFT ? (sp >> 32) : (sp & 0xffffffffull));
+  }
+  size_t wlo = slo << 6, whi = wlo + 64;
   if (whi > nwords) whi = nwords;
   while (whi - wlo > 1) {                        // largest word with prefix <= r (skips empty words)
     const size_t mid = (wlo + whi) >> 1;
-    if (((prefix[mid] >> SHIFT) & 0xffffu) <= r) wlo = mid; else whi = mid;
+    if (((a.prefix[mid] >> SHIFT) & 0xffffu) <= r) wlo = mid; else whi = mid;
   }
-  within = r - ((prefix[wlo] >> SHIFT) & 0xffffu);
+  within = r - ((a.prefix[wlo] >> SHIFT) & 0xffffu);
   return wlo;
 }
 
-// head table by search: entry t = the word that produces output 64 t.  One lane per ENTRY (outputs/64 of them)
-// instead of one lane per word of the volume: ~24 dependent L2 reads each, but only a few hundred thousand lanes.
+// head table: entry t = the word that produces output 64 t.  One lane per ENTRY (outputs/64 of them): ~25 dependent
+// L2 reads each, but only a few hundred thousand lanes.
 template <int SHIFT>
-__global__ __launch_bounds__(256) void k_heads_search(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
-                                                      size_t nseg, size_t nwords, u64 nHeads, u32 *__restrict__ head) {
+__global__ __launch_bounds__(256) void k_heads_search(EmitArgs a, size_t nwords, u64 nHeads, u32 *__restrict__ head) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nHeads) return;
   u32 within;
-  head[t] = (u32)locate_word<SHIFT>(segBase, prefix, nseg, nwords, t * 64, within);
+  head[t] = (u32)locate_word<SHIFT>(a, nwords, t * 64, within);
 }
 
+// Per-wave form of the search: a wave holds 64 consecutive outputs, which come from a short run of words:
+// `head[o/64]` names the word that produces output o & ~63; the 64 lanes load the absolute prefixes of the 64 words
+// from there on and each lane finds its own word with a 6-step shuffle search -- two dependent memory round trips
+// instead of the ~25 of a per-lane search.  Outputs that lie beyond the window (sparse surface) slide the window;
+// after a few slides the lane falls back to locate_word.
 // All 64 lanes of the wave must call this together (idx = consecutive outputs, `valid` lanes only).
 template <int SHIFT>
-__device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBase, const u32 *__restrict__ prefix,
-                                                   const u32 *__restrict__ head, size_t nseg, size_t nwords, u64 idx,
+__device__ __forceinline__ size_t locate_word_wave(const EmitArgs &a, const u32 *__restrict__ head, size_t nwords, u64 idx,
                                                    bool valid, u32 &within) {
   const int lane = threadIdx.x & 63;
   const u64 first = __shfl(idx, 0, 64);          // lane 0 is always valid; first is a multiple of 64
@@ -776,7 +847,7 @@ __device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBa
   bool done = !valid;
   for (int slide = 0; slide < 4; slide++) {
     const size_t w = w0 + lane;
-    const u64 A = (w < nwords) ? segBase[w >> 6] + ((prefix[w] >> SHIFT) & 0xffffu) : ~0ull;
+    const u64 A = (w < nwords) ? seg_base<SHIFT>(a, w) + ((a.prefix[w] >> SHIFT) & 0xffffu) : ~0ull;
     // first output of word w relative to the wave's first output: the head word starts at most one word's
     // worth (< 2^16) below it, everything that matters is <= 63, so 32 bits hold it exactly (large values clamp)
     const long long rel = (long long)(A - first);
@@ -794,20 +865,25 @@ __device__ __forceinline__ size_t locate_word_wave(const u64 *__restrict__ segBa
     if (!__ballot(!done)) return found;
     w0 += 63;
   }
-  if (!done) found = locate_word<SHIFT>(segBase, prefix, nseg, nwords, idx, within);
+  if (!done) found = locate_word<SHIFT>(a, nwords, idx, within);
   return found;
 }
 
-// K3a, global form: one lane per vertex, wave-window search.
-__global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Geo geo, size_t nseg, size_t nwords, u64 nV) {
+// K3a, search form (the fallback when the vertex-word queue could not be had): one lane per vertex, per-wave
+// window search through the head table, or a per-lane search without it.  Covers the counted range (a slab's
+// ghost slice included: the rank above needs those coordinates for the triangle split of its first slice).
+__global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Geo geo, size_t nwords, u64 nV) {
   const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u32 r = 0;
-  const size_t gi = locate_word_wave<0>(a.segBaseV, a.prefix, a.headV, nseg, nwords, v, v < nV, r);
+  size_t gi;
+  if (a.headV) gi = locate_word_wave<0>(a, a.headV, nwords, v, v < nV, r);
+  else gi = v < nV ? locate_word<0>(a, nwords, v, r) : 0;
   if (v >= nV) return;
   int k, y, z;
   word_coords(g, gi, k, y, z);
   WordInfo w;
-  classify_word(a.bits, a.alias, g, y, z, k, w);
+  u32 unk;
+  classify_word<false>(a.bits, a.occ, g, a.q1, y, z, k, w, unk);
   int lo = 0, hi = 64;                           // largest bit position with (#created before it) <= r
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -827,54 +903,18 @@ __global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Ge
   const int cx = k * 64 + lo + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
   float p[3];
   corner_point(geo, cx, cy, g.zglob0 + cz, p);
-  float *dst = a.points + 3 * v;
+  float *dst = a.points + 3 * v;                 // ghost points first, owned points from 3*V0 on
   dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
   if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
 }
 
-// K3a, queue form: one lane per word that creates vertices (the queue k_count left, dense in lanes and
-// unordered: a word's vertex ids follow from its own prefix).  The word is classified ONCE and the lane
-// walks its created corners in id order -- voxel by voxel, corner 0..7 -- writing the lattice points
-// and the dense corner map.  Lanes of a wave write neighbouring id ranges.
-__global__ __launch_bounds__(256) void k_emit_points_queue(EmitArgs a, Grid g, Geo geo, const u32 *__restrict__ vqueue,
-                                                           u32 nVertexWords) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nVertexWords) return;
-  const u32 gi = vqueue[t];
-  const u32 row = gi / (u32)g.W;                 // (measured: the shift form of word_coords is slower in this kernel)
-  const int k = (int)(gi - row * (u32)g.W);
-  const u32 zz = row / (u32)g.ny;
-  const int y = (int)(row - zz * (u32)g.ny), z = g.cz0 + (int)zz;
-  WordInfo w;
-  classify_word(a.bits, a.alias, g, y, z, k, w);
-  u64 v = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);       // id of this word's first vertex
-  u64 any = w.C[0] | w.C[1] | w.C[2] | w.C[3] | w.C[4] | w.C[5] | w.C[6] | w.C[7];
-  while (any) {
-    const int bx = __ffsll((long long)any) - 1;
-    any &= any - 1;
-    unsigned cm = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) cm |= (unsigned)((w.C[i] >> bx) & 1ull) << i;
-    while (cm) {
-      const int e = kCornerEnc[__ffs((int)cm) - 1];
-      cm &= cm - 1;
-      const int cx = k * 64 + bx + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
-      float p[3];
-      corner_point(geo, cx, cy, g.zglob0 + cz, p);
-      float *dst = a.points + 3 * v;
-      dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
-      if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
-      v++;
-    }
-  }
-}
-
-// K3a, queue form in two phases per wave.  Phase 1, one lane per vertex word: classify, count, wave scan, and a
+// K3a, queue form in two phases per wave (the queue k_count left is dense in lanes and unordered: a word's vertex
+// ids follow from its own prefix).  Phase 1, one lane per vertex word: classify, count, wave scan, and a
 // walk that only writes 2-byte descriptors (source lane, voxel, corner) into LDS in id order.  Phase 2, one lane
 // per VERTEX: descriptor -> lattice point, point store (lanes of one word hold consecutive ids: runs of
 // contiguous 12-byte stores), corner-map store.  The point arithmetic and the stores, the expensive part, run on
 // full waves instead of on the few lanes that still have vertices left.  A wave with more vertices than its LDS
-// slice holds (cannot happen on smooth surfaces) walks and stores directly, as k_emit_points_queue does.
+// slice holds (cannot happen on smooth surfaces) walks and stores directly.
 constexpr int POINTS_CAP = 1024;                 // descriptors per wave
 
 __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, Geo geo, const u32 *__restrict__ vqueue,
@@ -898,8 +938,9 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
     const u32 zz = row / (u32)g.ny;
     y = (int)(row - zz * (u32)g.ny);
     z = g.cz0 + (int)zz;
-    classify_word(a.bits, a.alias, g, y, z, k, w);
-    v0 = a.segBaseV[gi >> 6] + (a.prefix[gi] & 0xffffu);       // id of this word's first vertex
+    u32 unk;
+    classify_word<false>(a.bits, a.occ, g, a.q1, y, z, k, w, unk);
+    v0 = seg_base<0>(a, gi) + (a.prefix[gi] & 0xffffu);        // id of this word's first vertex
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt += (u32)popc64(w.C[i]);
   }
@@ -952,23 +993,12 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
   }
 }
 
-// the six face masks of a word only (7 bit-rows instead of 27)
-__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
-  const Rows3 c = load_row(bits, g, y, z, k);
-  const u64 *base = bits + k;
-  const size_t rs = (size_t)g.W;
-  const u64 ym = base[((size_t)z * g.ny + clampi(y - 1, 0, g.ny - 1)) * rs];
-  const u64 yp = base[((size_t)z * g.ny + clampi(y + 1, 0, g.ny - 1)) * rs];
-  const u64 zm = base[((size_t)clampi(z - 1, 0, g.nzb - 1) * g.ny + y) * rs];
-  const u64 zp = base[((size_t)clampi(z + 1, 0, g.nzb - 1) * g.ny + y) * rs];
-  F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
-}
-
 // one quad (or its two triangles): corner ids from the dense map, Q1 redirect, fused diagonal split
 template <bool TRI, bool MAP>
 __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 V0,
                                               u64 (&o)[TRI ? 6 : 4]) {
-  const int zp = a.alias[z];
+  u32 unk;
+  const int zp = alias_of(a.occ, g, a.q1, z, unk);
   u64 lid[4];                                    // vertex index in the counted range
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -1021,7 +1051,7 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
 // K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
 // (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
 template <bool TRI, bool MAP>
-__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nseg, size_t nwords, u64 nQ) {
+__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nwords, u64 nQ) {
   constexpr int NV = TRI ? 6 : 4;                // ids per quad
   // a lane's NV ids are 32 or 48 contiguous bytes, a wave's 64 quads 2 or 3 KiB: staged through LDS so that the
   // wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
@@ -1034,8 +1064,8 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
   u32 r = 0;
   size_t gi;
-  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a.segBaseQ, a.prefix, a.headQ, nseg, nwords, q + Q0, valid, r);
-  else gi = valid ? locate_word<16>(a.segBaseQ, a.prefix, nseg, nwords, q + Q0, r) : 0;
+  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a, a.headQ, nwords, q + Q0, valid, r);
+  else gi = valid ? locate_word<16>(a, nwords, q + Q0, r) : 0;
   if (valid) {
     int k, y, z;
     word_coords(g, gi, k, y, z);
@@ -1538,7 +1568,8 @@ static int occupancy_shift(const Grid &g) {
 }
 
 // classify slices [z0, z1) of the buffer (a z-range is a contiguous range of voxels and of words)
-hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, double iso, int z0, int z1, hipStream_t s) {
+hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, double iso, int z0, int z1, const Tuning &tn,
+                           hipStream_t s) {
   if (z1 <= z0) return hipSuccess;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
@@ -1551,31 +1582,29 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
     if (g.nx % 64 == 0 && aligned) {
       constexpr int VPL = 16 / sizeof(T);
       const u64 nwordsAll = nrows * g.W;
-      const u64 nchunks = nwordsAll / VPL;        // whole 1 KiB chunks; the < VPL words left go below
-      static const int variant = getenv("CUBERILLE_CLASSIFY_VARIANT") ? atoi(getenv("CUBERILLE_CLASSIFY_VARIANT")) : 3;
-      static const int gridCap = getenv("CUBERILLE_CLASSIFY_GRID") ? atoi(getenv("CUBERILLE_CLASSIFY_GRID")) : 2048;
-      if (nchunks) {
-        // 256 CUs x 8 blocks of 256 threads; grid-stride over the rest
-        auto go = [&](auto uTag, auto ntTag) {
-          constexpr int U = decltype(uTag)::value;
-          constexpr bool NT = decltype(ntTag)::value;
-          const unsigned blocks = grid_for((nchunks + U - 1) / U * 64, 256, gridCap);
-          hipLaunchKernelGGL((k_classify_flat<T, U, NT>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nchunks, iso, w.sliceOcc,
-                             occupancy_shift(g));
-        };
-        switch (variant) {
-          case 1: go(std::integral_constant<int, 4>(), std::true_type()); break;
-          case 2: go(std::integral_constant<int, 8>(), std::false_type()); break;
-          case 3: go(std::integral_constant<int, 8>(), std::true_type()); break;
-          case 4: go(std::integral_constant<int, 2>(), std::false_type()); break;
-          case 0: go(std::integral_constant<int, 4>(), std::false_type()); break;
-          default: go(std::integral_constant<int, 8>(), std::true_type()); break;   // measured best: 8 KiB per wave trip, nontemporal
-        }
+      const int lg = occupancy_shift(g);
+      // large ranges: whole spans through the staged write-through kernel (below ~256 MiB the caches absorb the
+      // word stores and more, smaller workgroups fill the chip better)
+      u64 spanWords = 0;
+      if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
+        const u64 nspans = nwordsAll / SPAN_WORDS;
+        const unsigned blocks = (unsigned)(nspans < (u64)(tn.classify_grid > 0 ? tn.classify_grid : 1024)
+                                               ? nspans : (u64)(tn.classify_grid > 0 ? tn.classify_grid : 1024));
+        hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, w.sliceOcc, lg);
+        spanWords = nspans * SPAN_WORDS;
       }
-      if (nchunks * VPL < nwordsAll)
-        hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, nchunks * VPL, nrows,
+      const u64 restWords = nwordsAll - spanWords;
+      const u64 nchunks = restWords / VPL;        // whole 1 KiB chunks; the < VPL words left go below
+      if (nchunks) {
+        // 256 CUs x 8 blocks of 256 threads; grid-stride over the rest; 8 KiB per wave trip, nontemporal
+        const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, tn.classify_grid > 0 ? tn.classify_grid : 2048);
+        hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, vox + spanWords * 64, w.bits + spanWords,
+                           nchunks, iso, w.sliceOcc, lg, spanWords);
+      }
+      if (spanWords + nchunks * VPL < nwordsAll)
+        hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, spanWords + nchunks * VPL, nrows,
                            (u64)g.ny, iso, w.sliceOcc);
-    } else if (wAll.flatBits && ((uintptr_t)vox % sizeof(T)) == 0 && !getenv("CUBERILLE_NO_STREAM_CLASSIFY")) {
+    } else if (wAll.flatBits && ((uintptr_t)vox % sizeof(T)) == 0 && !tn.no_stream_classify) {
       // ragged rows: flat stream of aligned 16-byte vectors (the first and last vector may reach up to 15 bytes
       // outside the range -- same 16-byte granule as valid voxels, so the loads cannot fault, and those bits
       // are never used), then cut into rows.  Each z-range uses its own part of the scratch.
@@ -1589,7 +1618,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       if (nchunks) {
         const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, 2048);
         hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, abase, flat, nchunks, iso,
-                           (u32 *)nullptr, -1);
+                           (u32 *)nullptr, -1, (u64)0);
       }
       if (nvec % 64) hipLaunchKernelGGL((k_classify_tail<T>), dim3(1), dim3(64), 0, s, abase, flat, nchunks * 64, nvec, iso);
       hipLaunchKernelGGL(k_repack_rows, dim3(grid_for(nrows * g.W, 256, 0)), dim3(256), 0, s, flat, w.bits, g.nx, g.W, nrows, skew);
@@ -1603,55 +1632,26 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
   });
 }
 
-hipError_t launch_alias(const Workspace &w, const Grid &g, int q1, hipStream_t s) {
+// per-slice occupancy from the packed bits where the sweep could not set it on the fly
+hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s) {
   if (occupancy_shift(g) < 0 || ((uintptr_t)w.vox % 16) != 0)
     hipLaunchKernelGGL(k_occupancy, dim3(g.nzb), dim3(256), 0, s, w.bits, (size_t)g.ny * g.W, w.sliceOcc);
-  hipLaunchKernelGGL(k_alias, dim3((g.nzb + 255) / 256), dim3(256), 0, s, w.sliceOcc, w.alias, g, q1, w.totals);
   return hipGetLastError();
 }
 
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
-  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.alias, g, nwords, w.prefix, w.segV, w.segQ,
-                     nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
+  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot,
+                     w.blockBase, nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
   return hipGetLastError();
 }
 
-size_t scan_temp_bytes(size_t nseg) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const u64 *)nullptr, (u64 *)nullptr, (int)nseg);
-  return bytes;
-}
-
-hipError_t launch_scan(void *temp, size_t tempBytes, const u64 *in, u64 *out, size_t n, hipStream_t s) {
-  return hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, out, (int)n, s);
-}
-
-hipError_t launch_heads(const Workspace &w, size_t nwords, u64 totV, u64 totQ, hipStream_t s) {
-  if (!w.headQ) return hipSuccess;
-  static const int bySearch = getenv("CUBERILLE_HEADS_SWEEP") ? 0 : 1;
-  if (bySearch) {
-    const size_t nseg = (nwords + 63) >> 6;
-    const u64 nHQ = (totQ + 63) / 64, nHV = w.headV ? (totV + 63) / 64 : 0;
-    if (nHQ) hipLaunchKernelGGL((k_heads_search<16>), dim3(grid_for(nHQ, 256, 0)), dim3(256), 0, s, w.segBaseQ, w.prefix, nseg, nwords, nHQ, w.headQ);
-    if (nHV) hipLaunchKernelGGL((k_heads_search<0>), dim3(grid_for(nHV, 256, 0)), dim3(256), 0, s, w.segBaseV, w.prefix, nseg, nwords, nHV, w.headV);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(k_heads, dim3(grid_for(nwords, 256, 0)), dim3(256), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ,
-                     nwords, w.headV, w.headQ);
-  return hipGetLastError();
-}
-
-hipError_t launch_finalize(const Workspace &w, const Grid &g, size_t nwords, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, w.prefix, w.segV, w.segQ, w.segBaseV, w.segBaseQ, g, nwords,
-                     w.totals);
-  return hipGetLastError();
-}
-
-static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
+static EmitArgs emit_args(const Workspace &w, const Grid &g, int q1, u64 pointOffset) {
   EmitArgs a;
-  a.bits = w.bits; a.alias = w.alias; a.prefix = w.prefix;
-  a.segBaseV = w.segBaseV; a.segBaseQ = w.segBaseQ; a.tot = w.totals;
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  a.bits = w.bits; a.occ = w.sliceOcc; a.q1 = q1; a.prefix = w.prefix;
+  a.segPre = w.segPre; a.blockBase = w.blockBase; a.nblk = (nwords + COUNT_WB - 1) / COUNT_WB;
+  a.tot = w.totals;
   a.points = w.points;
   a.cells = w.cells;
   a.pointOffset = pointOffset;
@@ -1660,64 +1660,59 @@ static EmitArgs emit_args(const Workspace &w, u64 pointOffset) {
   return a;
 }
 
-hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, u64 nV, u32 nVertexWords, hipStream_t s) {
-  if (!nV) return hipSuccess;
+hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, hipStream_t s) {
+  if (!w.headQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  static const int variant = getenv("CUBERILLE_POINTS_VARIANT") ? atoi(getenv("CUBERILLE_POINTS_VARIANT")) : 3;
-  if (w.vqueue && nwords < 0xffffffffULL && variant == 3) {
-    hipLaunchKernelGGL(k_emit_points_dense, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo,
-                       w.vqueue, nVertexWords);
-  } else if (w.vqueue && nwords < 0xffffffffULL && variant == 2) {
-    hipLaunchKernelGGL(k_emit_points_queue, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo,
-                       w.vqueue, nVertexWords);
-  } else if (w.headV && variant >= 1) {
-    const size_t nseg = (nwords + 63) >> 6;
-    hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, emit_args(w, 0), g, geo, nseg, nwords, nV);
-  } else {
-    const unsigned blocks = (unsigned)((nwords + EMIT_WB - 1) / EMIT_WB);
-    hipLaunchKernelGGL(k_emit_points, dim3(blocks), dim3(256), 0, s, emit_args(w, 0), g, geo, nwords);
-  }
+  const EmitArgs a = emit_args(w, g, 0, 0);
+  const u64 nHQ = (totQ + 63) / 64, nHV = w.headV ? (totV + 63) / 64 : 0;
+  if (nHQ) hipLaunchKernelGGL((k_heads_search<16>), dim3(grid_for(nHQ, 256, 0)), dim3(256), 0, s, a, nwords, nHQ, w.headQ);
+  if (nHV) hipLaunchKernelGGL((k_heads_search<0>), dim3(grid_for(nHV, 256, 0)), dim3(256), 0, s, a, nwords, nHV, w.headV);
   return hipGetLastError();
 }
 
-hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, u64 pointOffset, u64 nQ, hipStream_t s) {
+hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
+                              const Tuning &tn, hipStream_t s) {
+  if (!nV) return hipSuccess;
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const EmitArgs a = emit_args(w, g, q1, 0);
+  if (w.vqueue && nwords < 0xffffffffULL && tn.points_variant == 3)
+    hipLaunchKernelGGL(k_emit_points_dense, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
+  else
+    hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, a, g, geo, nwords, nV);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ, hipStream_t s) {
   if (!nQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const size_t nseg = (nwords + 63) >> 6;
-  const EmitArgs a = emit_args(w, pointOffset);
+  const EmitArgs a = emit_args(w, g, q1, pointOffset);
   const dim3 grid(grid_for(nQ, 256, 0)), block(256);
-  if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nseg, nwords, nQ);
-  else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nseg, nwords, nQ);
-  else if (a.cmap) hipLaunchKernelGGL((k_emit_cells<false, true>), grid, block, 0, s, a, g, nseg, nwords, nQ);
-  else hipLaunchKernelGGL((k_emit_cells<false, false>), grid, block, 0, s, a, g, nseg, nwords, nQ);
+  if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nwords, nQ);
+  else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nwords, nQ);
+  else if (a.cmap) hipLaunchKernelGGL((k_emit_cells<false, true>), grid, block, 0, s, a, g, nwords, nQ);
+  else hipLaunchKernelGGL((k_emit_cells<false, false>), grid, block, 0, s, a, g, nwords, nQ);
   return hipGetLastError();
 }
 
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const Params &p, u64 nPoints,
-                          u64 nGhost, hipStream_t s) {
+                          u64 nGhost, const Tuning &tn, hipStream_t s) {
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
   // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms
   // for one contiguous chunk of 256 per wave; u8 noise prefers contiguous, 2.23 vs 2.35 ms; earlier runs:
   // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)
-  u64 chunk = 128;
-  u64 gridWaves = 16384;
-  if (const char *e = getenv("CUBERILLE_PROJ_WAVES")) gridWaves = (u64)atoll(e);
-  int refill = 16;
-  if (const char *e = getenv("CUBERILLE_PROJ_REFILL")) refill = atoi(e);
-  static const int forceLiteral = getenv("CUBERILLE_PROJ_LITERAL") ? atoi(getenv("CUBERILLE_PROJ_LITERAL")) : 0;
-  int xcdRemap = 0;   // measured: remapping chunks per XCD is 1.6x SLOWER here (3.1 vs 1.9 ms), kept as a switch
-  if (const char *e = getenv("CUBERILLE_PROJ_XCD")) xcdRemap = atoi(e);
-  if (const char *e = getenv("CUBERILLE_PROJ_CHUNK")) { chunk = (u64)atoll(e); if (chunk < 64) chunk = 64; }
+  u64 chunk = tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk;
+  const u64 gridWaves = (u64)tn.proj_waves;
   while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
   u64 nwaves = (nPoints + chunk - 1) / chunk;
   if (gridWaves && nwaves > gridWaves) nwaves = gridWaves;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
+    // (giving each XCD a contiguous eighth of the vertex list was measured 1.6x slower: proj_xcd stays a switch)
     hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
-                       nPoints, nGhost, chunk, refill, xcdRemap, forceLiteral, w.totals);
+                       nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals);
     return hipGetLastError();
   });
 }

@@ -184,6 +184,25 @@ class Extractor:
         _abi.check(self._ctx, self._lib.cuberille_slice_occupancy(self._ctx, C.c_void_p(occ.ctypes.data), nz))
         return occ != 0
 
+    def slab_info(self):
+        """After count() on a slab: (alias_source_below_buffer, lowest_occupied_z, highest_occupied_z)."""
+        st = _abi.SlabStatus()
+        _abi.check(self._ctx, self._lib.cuberille_slab_info(self._ctx, C.byref(st)))
+        return bool(st.alias_source_below_buffer), int(st.lowest_occupied_z), int(st.highest_occupied_z)
+
+    def debug_option(self, name, value):
+        """Development switch of this context (cuberille_debug_set_option); "defaults" resets them all."""
+        _abi.check(self._ctx, self._lib.cuberille_debug_set_option(self._ctx, name.encode(), int(value)))
+
+
+def required_halo(desc, params):
+    """Slices a slab buffer must hold (below, above) its owned range for these parameters (needs no GPU)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    rc = _abi.lib().cuberille_required_halo(C.byref(desc), C.byref(params), C.byref(lo), C.byref(hi))
+    if rc != _abi.OK:
+        raise _abi.CuberilleError(rc, "cuberille_required_halo: bad image description or parameters")
+    return int(lo.value), int(hi.value)
+
 
 def _clamp(v, lo, hi):
     return lo if v < lo else (hi if v > hi else v)
@@ -211,7 +230,7 @@ class CuberilleImageToMeshFilter:
         self._iso = 1
         self._triangles = True
         self._project = True
-        self._threshold = 0.5
+        self._threshold = self._threshold_asked = 0.5
         self._step = -1.0
         self._relax = 0.95
         self._max_steps = 50
@@ -224,6 +243,7 @@ class CuberilleImageToMeshFilter:
             raise TypeError("SetInput expects an mha.Volume")
         self._input = image
         self._dtype = image.voxels.dtype
+        self._threshold = _clamp(self._threshold_asked, 0.0, _pixel_max(self._dtype))
 
     # h:180-181
     def SetIsoSurfaceValue(self, v):
@@ -258,9 +278,11 @@ class CuberilleImageToMeshFilter:
     def ProjectVerticesToIsoSurfaceOff(self):
         self._project = False
 
-    # h:209-210 clamp [0, max pixel]
+    # h:209-210 clamp [0, max pixel].  The reference knows the pixel type at compile time; here it is known once
+    # an input is set, so the upper clamp is (re)applied against the input's type by SetInput and Update
     def SetProjectVertexSurfaceDistanceThreshold(self, v):
-        self._threshold = _clamp(float(v), 0.0, _pixel_max(self._dtype))
+        self._threshold_asked = float(v)
+        self._threshold = _clamp(float(v), 0.0, _pixel_max(self._dtype) if self._input is not None else float("inf"))
 
     def GetProjectVertexSurfaceDistanceThreshold(self):
         return self._threshold

@@ -5,13 +5,15 @@ The reference has no distributed code.  The raster order of its sweep
 the volume into Z-slabs in rank order gives every rank a CONTIGUOUS, ORDERED range of
 vertex ids and of cell ids; the path needs exactly two exchanges:
 
-  1. halo: each rank receives `HALO` boundary slices from its two neighbours
+  1. halo: each rank receives `halo` boundary slices from its two neighbours
      (point-to-point send/recv: on GPUs each pair rides one direct xGMI link; this is
      a chain, not a ring collective).  2 slices below + 1 above are needed for the
      topology (ids of corners created one slice down); the projection walk can travel
-     ~4.8 voxels (step * sum(relax^k)), hence 8.
-  2. counts: one all-gather of (n_points, n_cells) per rank -> exclusive prefix = the
-     rank's id offsets.
+     step * sum(relax^k) / z-spacing slices (4.65 at the defaults), plus the interpolation
+     cell and the gradient ring: 8 at the defaults, more for long walks or thin slices --
+     the library computes it (cuberille_required_halo) and refuses a slab that holds less.
+  2. counts: one all-gather of (n_points, n_cells, ...) per rank -> exclusive prefix =
+     the rank's id offsets.
 
 Backend "nccl" is RCCL on ROCm; the same code runs under "gloo" on CPU tensors, which
 is how tests/test_distributed.py covers it without a GPU.
@@ -33,16 +35,15 @@ def buffer_range(global_nz, z0, z1, halo=HALO):
     return max(z0 - halo, 0), min(z1 + halo, int(global_nz))
 
 
-def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True):
+def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
     Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together.
     wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
-    import os
     import torch.distributed as dist
     if buf.is_cuda and dist.get_backend(group) == "gloo" and wait:
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
         host = buf.cpu()
-        exchange_halos(host, lo, hi, z0, z1, rank, world, group)
+        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo)
         if z0 > lo:
             buf[:z0 - lo].copy_(host[:z0 - lo])
         if hi > z1:
@@ -56,13 +57,13 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True):
         ops.append(dist.P2POp(dist.irecv, buf[z1 - lo:hi - lo], rank + 1, group))
     # what the neighbours miss: the upper neighbour wants my top `its_nlo` slices, the lower my bottom ones
     if rank < world - 1:
-        n = min(HALO, z1 - z0) if nhi > 0 else 0
+        n = min(halo, z1 - z0) if nhi > 0 else 0
         if n > 0:
             t = buf[z1 - lo - n:z1 - lo].contiguous()
             keep.append(t)
             ops.append(dist.P2POp(dist.isend, t, rank + 1, group))
     if rank > 0:
-        n = min(HALO, z1 - z0) if nlo > 0 else 0
+        n = min(halo, z1 - z0) if nlo > 0 else 0
         if n > 0:
             t = buf[z0 - lo:z0 - lo + n].contiguous()
             keep.append(t)
@@ -75,17 +76,18 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True):
     return buf
 
 
-def gather_counts(n_points, n_cells, device, group=None):
-    """All-gather of every rank's (n_points, n_cells); returns an int64 array [world, 2]."""
+def gather_counts(n_points, n_cells, device, group=None, extra=()):
+    """All-gather of every rank's (n_points, n_cells, *extra); returns an int64 array [world, 2 + len(extra)]."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":
         device = "cpu"
-    mine = torch.tensor([int(n_points), int(n_cells)], dtype=torch.int64, device=device)
-    out = torch.empty(world * 2, dtype=torch.int64, device=device)
+    row = [int(n_points), int(n_cells)] + [int(v) for v in extra]
+    mine = torch.tensor(row, dtype=torch.int64, device=device)
+    out = torch.empty(world * len(row), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, mine, group=group)
-    return out.cpu().numpy().reshape(world, 2)
+    return out.cpu().numpy().reshape(world, len(row))
 
 
 class _DeviceArray:
@@ -138,64 +140,97 @@ class ShardedExtractor:
     """Multi-GPU driver: one instance per rank, wraps one Extractor."""
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
-                 origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=False):
+                 origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None):
+        """params: the extraction parameters the slabs will be used with -- the halo is sized for them
+        (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
+        check_aliasing: raise when quirk Q1 (vertex re-use across an empty slice) would cross a slab boundary
+        instead of returning a mesh that differs from the single-GPU one; costs nothing extra (the flags ride
+        in the count all-gather)."""
         from . import _abi
-        from .cuberille import make_desc
+        from .cuberille import make_desc, required_halo
         self.ex = extractor
         self.rank, self.world, self.group = rank, world, group
         self.nx, self.ny, self.nz = (int(v) for v in global_dims)
         self.z0, self.z1 = slab_range(self.nz, world, rank)
-        self.lo, self.hi = buffer_range(self.nz, self.z0, self.z1)
-        if world > 1 and self.z1 - self.z0 < HALO:
-            raise ValueError("slabs thinner than the halo (%d slices) are not supported" % HALO)
+        self._geo = (np_dtype, spacing, origin, direction)
+        if halo is None:
+            halo = HALO
+            if params is not None:
+                halo = max(required_halo(make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction), params))
+        self.halo = int(halo)
+        self.lo, self.hi = buffer_range(self.nz, self.z0, self.z1, self.halo)
+        if world > 1 and self.z1 - self.z0 < self.halo:
+            raise ValueError("slabs thinner than the halo (%d slices) are not supported" % self.halo)
         self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
-        self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None)
+        self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None, None)
         self._halo_event = None
+        self._vox_event = None
         self.check_aliasing = check_aliasing
         self.counts = None
 
     def extract(self, buf, params):
-        """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid.  Runs halo exchange,
-        count, the count all-gather and emit; leaves this rank's mesh part on its device."""
+        """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid (written on torch's current stream).
+        Runs halo exchange, count, the count all-gather and emit; leaves this rank's mesh part on its device."""
         import os
         import torch
         import torch.distributed as dist
+        from . import _abi
+        from .cuberille import required_halo
         keep = None
         if self.world > 1:
+            need = max(required_halo(self.desc, params))
+            if need > self.halo:
+                raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "
+                                 "with a halo of %d (pass params= or halo= to its constructor)" % (need, self.halo))
             # (CUBERILLE_FORCE_EVENT_PATH: take this branch under gloo too -- test hook for one-GPU boxes)
             if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or os.environ.get("CUBERILLE_FORCE_EVENT_PATH")):
-                # RCCL: do not wait on the host.  req.wait() only orders torch's current stream behind the
-                # transfer; an event recorded there tells the library when the halo slices are in, and it
-                # thresholds the owned slices meanwhile.
-                reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
-                                            wait=False)
-                for req in reqs:
-                    req.wait()
-                if self._halo_event is None:
+                # RCCL: do not wait on the host.  The library runs on its own stream: one event tells it when the
+                # owned slices (produced on torch's current stream) are valid, a second one, recorded behind the
+                # transfers, when the halo slices are in; it thresholds the owned slices meanwhile.
+                if self._vox_event is None:
+                    self._vox_event = torch.cuda.Event()
                     self._halo_event = torch.cuda.Event()
+                self._vox_event.record(torch.cuda.current_stream())
+                reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
+                                            wait=False, halo=self.halo)
+                for req in reqs:
+                    req.wait()                     # orders torch's current stream behind the transfer, not the host
                 self._halo_event.record(torch.cuda.current_stream())
+                self.slab.voxels_ready_event = self._vox_event.cuda_event
                 self.slab.halo_ready_event = self._halo_event.cuda_event
             else:
-                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group)
+                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=self.halo)
                 if buf.is_cuda:
                     torch.cuda.current_stream().synchronize()
                 self.slab.halo_ready_event = None
-        n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab if self.world > 1 else None)
-        del keep
-        if self.world > 1:
-            self.counts = gather_counts(n_p, n_c, buf.device, self.group)
-            poff, coff = id_offsets(self.counts, self.rank)
-            if self.check_aliasing:
-                occ_local = self.ex.slice_occupancy(self.hi - self.lo)[self.z0 - self.lo:self.z1 - self.lo]
-                occ = [None] * self.world
-                dist.all_gather_object(occ, occ_local, group=self.group)
-                bounds = [slab_range(self.nz, self.world, r) for r in range(self.world)]
-                bad = aliasing_crosses_slabs(np.concatenate(occ), bounds)
-                if bad >= 0:
-                    raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses a slab boundary at z=%d" % bad)
-        else:
+                self.slab.voxels_ready_event = None
+        elif buf.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        if self.world == 1:
+            n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, None)
             self.counts = np.array([[n_p, n_c]], dtype=np.int64)
-            poff, coff = 0, 0
+            return self.ex.emit(0, 0)
+        # a failure on one rank must not leave the others waiting in the all-gather: it travels with the counts
+        n_p = n_c = 0
+        soft, top, failed = False, -1, None
+        try:
+            n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab)
+            if self.check_aliasing and params.emulate_empty_slice_aliasing:
+                soft, _, top = self.ex.slab_info()
+        except _abi.CuberilleError as e:
+            failed = e
+        del keep
+        rows = gather_counts(n_p, n_c, buf.device, self.group, extra=(int(soft), top, 0 if failed is None else 1))
+        self.counts = rows[:, :2]
+        if rows[:, 4].any():
+            bad = [int(r) for r in np.nonzero(rows[:, 4])[0]]
+            raise RuntimeError("cuberille_count failed on rank(s) %s%s" % (bad, ": %s" % failed if failed is not None else ""))
+        if self.check_aliasing:
+            for r in range(1, self.world):
+                # rank r assumed that nothing is occupied below its buffer; a rank below says otherwise
+                if rows[r, 2] and (rows[:r, 3] >= 0).any():
+                    raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % r)
+        poff, coff = id_offsets(self.counts, self.rank)
         return self.ex.emit(poff, coff)
 
     def gather_mesh(self, dst=0, on_device=None):

@@ -346,19 +346,28 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
     assert_same_mesh(m, ref)
 
 
-@pytest.mark.parametrize("env", ["CUBERILLE_NO_CMAP", "CUBERILLE_NO_HEADS", "CUBERILLE_NO_VQUEUE"])
-def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, monkeypatch, env):
-    """When the dense corner map (4 B per lattice corner) or the head tables cannot be allocated the
-    kernels recompute ids / search the prefix arrays instead; same mesh either way."""
-    monkeypatch.setenv(env, "1")
+@pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"),
+                                     ("no_cmap", "no_heads", "no_vqueue"), ("proj_phase_a",), ("classify_variant",)])
+def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, options):
+    """When the dense corner map (4 B per lattice corner), the head tables or the vertex-word queue cannot be
+    allocated the kernels recompute ids / search the prefix arrays instead; the projection also runs without its
+    dense first phase and the sweep without its staged spans; same mesh every way.  The switches are per-context
+    options of the C ABI (cuberille_debug_set_option), not environment variables."""
     rng = np.random.default_rng(11)
     vox = rng.integers(0, 255, size=(9, 10, 130), dtype=np.uint8)
     vox[4] = 0                                    # an empty slice: exercises the aliasing redirect too
-    for vol, iso in [(volumes("nucleon.mha"), 128), (volumes("silicium.mha"), 85), (pkg.Volume(vox), 128)]:
-        for tri in (0, 1):
-            kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
-            mesh = run_gpu(pkg, extractor, vol, iso, **kw)
-            assert_same_mesh(mesh, oracle.run(vol.voxels, iso, **kw))
+    try:
+        for o in options:
+            extractor.debug_option(o, 0 if o == "proj_phase_a" else 1)
+        for vol, iso in [(volumes("nucleon.mha"), 128), (volumes("silicium.mha"), 85), (pkg.Volume(vox), 128)]:
+            for tri in (0, 1):
+                kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+                mesh = run_gpu(pkg, extractor, vol, iso, **kw)
+                assert_same_mesh(mesh, oracle.run(vol.voxels, iso, **kw))
+    finally:
+        extractor.debug_option("defaults", 0)
+    with pytest.raises(pkg._abi.CuberilleError):
+        extractor.debug_option("no_such_switch", 1)
 
 
 def _closed_form_counts_torch(ins):
@@ -692,7 +701,7 @@ def test_rccl_and_library_share_one_process(tmp_path):
 def test_ragged_rows_at_every_pointer_alignment(pkg, oracle, extractor, dtype):
     """Rows that are not whole 64-voxel words go through the flat-stream threshold + row repack; the stream
     starts at the 16-byte boundary below the first voxel, so every misalignment of the device pointer (and
-    the old one-voxel-per-lane kernel, CUBERILLE_NO_STREAM_CLASSIFY) must give the oracle's mesh."""
+    the old one-voxel-per-lane kernel, option no_stream_classify) must give the oracle's mesh."""
     import torch
     rng = np.random.default_rng(11)
     item = np.dtype(dtype).itemsize
@@ -709,12 +718,12 @@ def test_ragged_rows_at_every_pointer_alignment(pkg, oracle, extractor, dtype):
             torch.cuda.synchronize()
             extractor.extract_device(raw.data_ptr() + skew, desc, prm)
             assert_same_mesh(extractor.download(), want)
-    os.environ["CUBERILLE_NO_STREAM_CLASSIFY"] = "1"
+    extractor.debug_option("no_stream_classify", 1)
     try:
         extractor.extract_device(raw.data_ptr() + skew, desc, prm)
         assert_same_mesh(extractor.download(), want)
     finally:
-        del os.environ["CUBERILLE_NO_STREAM_CLASSIFY"]
+        extractor.debug_option("defaults", 0)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -23,13 +23,14 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == 3
+    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header(pkg):
     assert C.sizeof(pkg._abi.ImageDesc) == 8 + 24 + 24 + 24 + 72
     assert C.sizeof(pkg._abi.Params) == 8 + 8 + 8 + 8 + 8 + 8
-    assert C.sizeof(pkg._abi.Slab) == 56
+    assert C.sizeof(pkg._abi.Slab) == 64
+    assert C.sizeof(pkg._abi.SlabStatus) == 24
     assert C.sizeof(pkg._abi.Result) == 8 + 8 + 8 + 7 * 4 + 4 + 8
 
 
@@ -43,6 +44,58 @@ def test_no_device_means_error_not_fallback(pkg):
     f.SetInput(pkg.Volume(np.zeros((4, 4, 4), dtype=np.uint8)))
     with pytest.raises(pkg._abi.CuberilleError):
         f.Update()
+
+
+def test_contexts_from_two_threads(pkg):
+    """include/cuberille_hip.h: distinct contexts are independent, also while they are being created and destroyed
+    on different threads; the text of a failed create is kept per thread.  Without a GPU every create fails with
+    CUBERILLE_ERR_NO_DEVICE and its own message; with one, every thread gets a working context."""
+    import threading
+    lib = pkg._abi.lib()
+    out = {}
+
+    def work(i):
+        res = []
+        for _ in range(20):
+            ctx = C.c_void_p()
+            rc = lib.cuberille_create(C.byref(ctx), 0)
+            text = lib.cuberille_last_error(None) if rc else b""
+            res.append((rc, bytes(text)))
+            if rc == 0:
+                assert lib.cuberille_debug_set_option(ctx, b"no_cmap", 1) == 0
+                lib.cuberille_destroy(ctx)
+        out[i] = res
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        for rc, text in out[i]:
+            if _has_gpu(pkg):
+                assert rc == 0
+            else:
+                assert rc == pkg._abi.ERR_NO_DEVICE and b"no CPU fallback" in text
+
+
+def test_library_never_reads_the_environment():
+    """Tuning and test switches go through cuberille_debug_set_option: no getenv in the product sources."""
+    csrc = os.path.join(ROOT, "midas-journal-740_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
+
+
+def test_required_halo_follows_the_parameters(pkg):
+    """cuberille_required_halo (host arithmetic, no GPU): 8 slices for the defaults on unit spacing; thin slices,
+    a longer step or more steps need more; projection off needs the topology's 2 / 1 only."""
+    d = pkg.make_desc(np.float32, (64, 64, 64))
+    assert pkg.required_halo(d, pkg.make_params(0.5)) == (8, 8)
+    assert pkg.required_halo(d, pkg.make_params(0.5, project=False)) == (2, 1)
+    thin = pkg.make_desc(np.float32, (64, 64, 64), spacing=(1.0, 1.0, 0.25))
+    assert pkg.required_halo(thin, pkg.make_params(0.5)) == (22, 22)
+    assert pkg.required_halo(d, pkg.make_params(0.5, step=1.0, relax=1.0, max_steps=10))[0] == 12 + 3
+    assert pkg.required_halo(d, pkg.make_params(0.5, step=0.25, relax=0.95, max_steps=0))[0] == 1 + 3
 
 
 def test_product_never_imports_the_oracle():
