@@ -45,8 +45,8 @@ struct Totals {        // device-resident, zeroed before every count, mirrored t
   u64 g0pre;           // in-block prefix (V | Q << 32) at the first owned word, left by the count block that holds it
   u32 err;             // device-side error flags
   u32 nVertexWords;    // entries in the vertex-word queue (words that create at least one vertex)
-  u32 ticket;          // count blocks that have published their totals (the last one scans them)
   u32 nSurvivors;      // projection: vertices the dense first phase handed on to the refilling walk
+  u32 pad_;
 };
 
 enum {
@@ -66,8 +66,8 @@ struct Workspace {     // device pointers valid for one count/emit pair
   u32 *sliceOcc;       // per buffer slice: does it hold an inside voxel (quirk Q1 needs it)
   u32 *prefix;         // per counted word: exclusive in-segment prefix, V | Q<<16
   u64 *segPre;         // per 64-word segment: exclusive in-block prefix, V | Q<<32
-  u64 *blockTot;       // per count block: its totals V | Q<<32, published with agent-scope atomics
-  u64 *blockBase;      // per count block: absolute exclusive prefixes, [2b] = V, [2b+1] = Q (written by the last block)
+  u64 *blockTot;       // per count block: its totals V | Q<<32
+  u64 *blockBase;      // per count block: absolute exclusive prefixes, [2b] = V, [2b+1] = Q (k_block_scan)
   Totals *totals;
   float *points;
   u64 *cells;

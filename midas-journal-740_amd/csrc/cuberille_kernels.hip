@@ -413,56 +413,94 @@ struct WordInfo {
 
 struct Neigh {
   u64 raw[3][3][3];  // [dz+1][dy+1][dx+1] bit x: inside(x+dx, y+dy, z+dz), every coordinate clamped into the image
-  u64 e[3][3][3];    // the same AND "that voxel exists" (off the image: 0)
+  u64 exm, exp_;     // bit x: voxel x-1 / x+1 exists (all ones except at the two ends of a row)
+  u32 exy[3], exz[3];  // all ones when row y+dy / slice z+dz exists, else 0 (only read on waves that touch a y/z border)
 };
 
 // block member E (code x|y<<1|z<<2) of the 2x2x2 block around corner D of voxel x sits at offset D - E per axis.
 // It activates the corner when it exists, is inside, and at least one of its three face neighbours inside the
-// block is outside: two 3-input operations per 32-bit half.
-template <int D, int E>
+// block is outside: two 3-input operations per 32-bit half.  The x existence is
+// applied by the caller to whole groups of terms (it only differs from all-ones at the row ends).
+template <bool YZ, int D, int E>
 __device__ __forceinline__ u64 act(const Neigh &n) {
   constexpr int sx = (D & 1) - (E & 1), sy = ((D >> 1) & 1) - ((E >> 1) & 1), sz = (D >> 2) - (E >> 2);
   constexpr int nx_ = (D & 1) - ((E ^ 1) & 1), ny_ = ((D >> 1) & 1) - (((E ^ 2) >> 1) & 1), nz_ = (D >> 2) - ((E ^ 4) >> 2);
   const u64 t = bop3<TT_AND3>(n.raw[sz + 1][sy + 1][nx_ + 1], n.raw[sz + 1][ny_ + 1][sx + 1], n.raw[nz_ + 1][sy + 1][sx + 1]);
-  return bop3<TT_A_ANDN_B>(n.e[sz + 1][sy + 1][sx + 1], t, t);
+  u64 a = bop3<TT_A_ANDN_B>(n.raw[sz + 1][sy + 1][sx + 1], t, t);
+  if (YZ && (sy != 0 || sz != 0)) {
+    const u32 ex = n.exy[sy + 1] & n.exz[sz + 1];
+    a &= (u64)ex | ((u64)ex << 32);
+  }
+  return a;
 }
-// OR of act<D,E'> over E' = E..7 (members with a larger code come earlier in raster order: smaller coordinates)
-template <int D, int E>
-__device__ __forceinline__ u64 act_from(const Neigh &n) {
+// OR of act<D,E'> over E' = E..7 with E' & 1 == PAR (members with a larger code come earlier in raster order:
+// smaller coordinates).  PAR == D & 1: members in the voxel's own x column (offset 0 in x); the others sit at
+// x-1 (D even) or x+1 (D odd).
+template <bool YZ, int D, int E, int PAR>
+__device__ __forceinline__ u64 act_or(const Neigh &n) {
   if constexpr (E > 7) return 0ull;
-  else if constexpr (E == 7) return act<D, 7>(n);
-  else if constexpr (E == 6) return act<D, 6>(n) | act<D, 7>(n);
-  else return bop3<TT_OR3>(act<D, E>(n), act<D, E + 1>(n), act_from<D, E + 2>(n));
+  else if constexpr ((E & 1) != PAR) return act_or<YZ, D, E + 1, PAR>(n);
+  else if constexpr (E + 2 > 7) return act<YZ, D, E>(n);
+  else if constexpr (E + 4 > 7) return act<YZ, D, E>(n) | act<YZ, D, E + 2>(n);
+  else return bop3<TT_OR3>(act<YZ, D, E>(n), act<YZ, D, E + 2>(n), act_or<YZ, D, E + 4, PAR>(n));
 }
-template <int I>
+template <bool YZ, int I>
 __device__ __forceinline__ u64 created(const Neigh &n) {
   constexpr int D = (I == 2) ? 3 : (I == 3) ? 2 : (I == 6) ? 7 : (I == 7) ? 6 : I;
-  if constexpr (D == 7) return act<7, 7>(n);
-  else return bop3<TT_A_ANDN_B>(act<D, D>(n), act_from<D, D + 1>(n), 0ull);
+  const u64 own = act<YZ, D, D>(n);
+  if constexpr (D == 7) return own;
+  else {
+    const u64 same = act_or<YZ, D, D + 1, (D & 1)>(n);
+    const u64 other = act_or<YZ, D, D + 1, 1 - (D & 1)>(n) & ((D & 1) ? n.exp_ : n.exm);
+    return bop3<0x10>(own, same, other);                 // own & ~(same | other)
+  }
 }
 
 // YZ: some lane of the wave sits on a y or z border of the buffer (then rows off the image must not activate
-// anything); interior waves skip those masks.  The x ends cost one mask on the shifted rows either way.
+// anything); interior waves skip those masks.
+// Loads: the nine words of the neighbourhood's rows, and the centre row's two x neighbours.  The x neighbours of the
+// other eight rows each contribute ONE bit (the carry into voxel 0 / 63), and those two voxels only matter when they
+// emit a face themselves (a voxel without a face creates no corner): the sixteen loads are issued for those lanes
+// only.  Returns the word's any-face mask; the caller ANDs it into the created masks, which also wipes whatever
+// the missing carries left in bits 0 and 63.
 template <bool YZ>
-__device__ __forceinline__ void load_neigh(const WordPos &w, const Grid &g, Neigh &n) {
+__device__ __forceinline__ u64 load_neigh(const WordPos &w, const Grid &g, Neigh &n) {
   const u64 valid = valid_mask(g, w.k);
-  const u64 exm = (w.k == 0) ? ~1ull : ~0ull;
-  const u64 exp_ = (w.k == g.W - 1) ? (valid >> 1) : ~0ull;
+  n.exm = (w.k == 0) ? ~1ull : ~0ull;
+  n.exp_ = (w.k == g.W - 1) ? (valid >> 1) : ~0ull;
+  if (YZ) {
+    n.exy[0] = w.y > 0 ? ~0u : 0u;            n.exy[1] = ~0u;  n.exy[2] = w.y < g.ny - 1 ? ~0u : 0u;
+    n.exz[0] = w.z > 0 ? ~0u : 0u;            n.exz[1] = ~0u;  n.exz[2] = w.z < g.nzb - 1 ? ~0u : 0u;
+  }
+  u64 c[3][3];
+#pragma unroll
+  for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) c[dz][dy] = w.q[w.yo[dy] + w.zo[dz]];
+  const bool first = w.k == 0, last = w.k == g.W - 1;
+  const u64 lastbit = 1ull << g.lastpos;
+  const u64 wp1 = w.q[w.km], wn1 = w.q[w.kp];
+  const u64 m11 = (c[1][1] << 1) | (first ? (c[1][1] & 1ull) : (wp1 >> 63));
+  const u64 p11 = (c[1][1] >> 1) | (last ? (c[1][1] & lastbit) : (wn1 << 63));
+  const u64 anyFace = c[1][1] & ~(m11 & p11 & c[1][0] & c[1][2] & c[0][1] & c[2][1]);
+  const bool needM = (anyFace & 1ull) && !first, needP = (anyFace >> 63) && !last;
 #pragma unroll
   for (int dz = 0; dz < 3; dz++)
 #pragma unroll
     for (int dy = 0; dy < 3; dy++) {
-      const Rows3 r = load_row(w, g, w.yo[dy] + w.zo[dz]);
-      n.raw[dz][dy][0] = r.m; n.raw[dz][dy][1] = r.c; n.raw[dz][dy][2] = r.p;
-      u64 rowex = ~0ull;
-      if (YZ) {
-        const bool ex = (dy == 1 || (dy == 0 ? w.y > 0 : w.y < g.ny - 1)) && (dz == 1 || (dz == 0 ? w.z > 0 : w.z < g.nzb - 1));
-        rowex = ex ? ~0ull : 0ull;
+      u64 m, p;
+      if (dz == 1 && dy == 1) { m = m11; p = p11; }
+      else {
+        const u64 cc = c[dz][dy];
+        u64 wp = 0, wn = 0;
+        if (needM) wp = w.q[w.yo[dy] + w.zo[dz] - 1];
+        if (needP) wn = w.q[w.yo[dy] + w.zo[dz] + 1];
+        m = (cc << 1) | (first ? (cc & 1ull) : (wp >> 63));
+        p = (cc >> 1) | (last ? (cc & lastbit) : (wn << 63));
       }
-      n.e[dz][dy][0] = r.m & exm & rowex;
-      n.e[dz][dy][1] = r.c & rowex;
-      n.e[dz][dy][2] = r.p & exp_ & rowex;
+      n.raw[dz][dy][0] = m; n.raw[dz][dy][1] = c[dz][dy]; n.raw[dz][dy][2] = p;
     }
+  return anyFace;
 }
 
 // AE[i] (i = 0..3) bit x: bottom corner i of voxel x already exists as a top-plane corner of the
@@ -496,7 +534,18 @@ __device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, cons
   const bool anyBorder = __ballot(yzBorder) != 0ull;      // uniform over the lanes that are here
   const WordPos wp = word_pos(bits, g, y, z, k);
   Neigh n;
-  if (anyBorder) load_neigh<true>(wp, g, n); else load_neigh<false>(wp, g, n);
+  u64 anyFace;
+  if (anyBorder) {
+    anyFace = load_neigh<true>(wp, g, n);
+    w.C[0] = created<true, 0>(n); w.C[1] = created<true, 1>(n); w.C[2] = created<true, 2>(n); w.C[3] = created<true, 3>(n);
+    w.C[4] = created<true, 4>(n); w.C[5] = created<true, 5>(n); w.C[6] = created<true, 6>(n); w.C[7] = created<true, 7>(n);
+  } else {
+    anyFace = load_neigh<false>(wp, g, n);
+    w.C[0] = created<false, 0>(n); w.C[1] = created<false, 1>(n); w.C[2] = created<false, 2>(n); w.C[3] = created<false, 3>(n);
+    w.C[4] = created<false, 4>(n); w.C[5] = created<false, 5>(n); w.C[6] = created<false, 6>(n); w.C[7] = created<false, 7>(n);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) w.C[i] &= anyFace;          // a voxel creates corners only on faces it emits
   if (FACES) {
     const u64 I = n.raw[1][1][1];
     w.F[0] = I & ~n.raw[1][1][0];   // -x   (offsets of txx:122-127)
@@ -506,8 +555,6 @@ __device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, cons
     w.F[4] = I & ~n.raw[0][1][1];   // -z
     w.F[5] = I & ~n.raw[2][1][1];   // +z
   }
-  w.C[0] = created<0>(n); w.C[1] = created<1>(n); w.C[2] = created<2>(n); w.C[3] = created<3>(n);
-  w.C[4] = created<4>(n); w.C[5] = created<5>(n); w.C[6] = created<6>(n); w.C[7] = created<7>(n);
   const int zp = alias_of(occ, g, q1, z, unknown);
   if (zp >= 0) {
     u64 AE[4];
@@ -533,30 +580,31 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
 //   phase 2  one lane per QUEUED word: the 8 created-corner masks (27 bit-rows) -> vertex count.  The surface
 //            touches a fraction of the words, so the expensive part runs on densely packed lanes.
 //   phase 3  one wave per segment: exclusive scan of the packed counts -> prefix; then the block's 32 segment
-//            totals are scanned -> segPre, and the block total is PUBLISHED: one agent-scope atomic exchange
-//            of V | Q<<32 into blockTot[b], then one atomic add on a ticket.
-//   phase 4  the block whose ticket is the last one reads all block totals back (agent-scope atomic loads:
-//            the exchanges and these loads meet at the memory side, no cache holds those lines), scans them and
-//            writes blockBase and the grand totals.  No look-back spinning: nobody ever waits for another block.
+//            totals are scanned -> segPre, and the block total goes to blockTot.
+// k_block_scan (one workgroup) then turns the block totals into blockBase and the grand totals.  (Doing that in
+// the last count block to arrive -- totals published with agent-scope atomics, a ticket counter -- works and was
+// measured: every block then sits on its CU for the ~5 us its returning atomics take, 0.05 ms in all at 1024^3
+// against 0.008 ms for this second launch: profiles/microbench/r2_count_sweep2.log.)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independent 32-bit sums packed lo | hi<<32
   return (u64)wave_inclusive_sum((u32)v) | ((u64)wave_inclusive_sum((u32)(v >> 32)) << 32);
 }
 
-__global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
+// (5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill too much)
+template <int MODE>   // 0 in the library; 2: no block scan, 4: no corner logic (profiles/microbench/count_sweep.hip)
+__global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
                                                size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
-                                               u64 *__restrict__ blockTot, u64 *__restrict__ blockBase,
-                                               u32 *__restrict__ vqueue, Totals *__restrict__ tot) {
+                                               u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
+                                               Totals *__restrict__ tot) {
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
   __shared__ unsigned short queue[COUNT_WB], vlist[COUNT_WB];
   __shared__ u64 segTot[COUNT_WB / 64];
-  __shared__ u64 lastSum[256];
   __shared__ int nQueued, nVertexWords;
-  __shared__ u32 vbase, g0InSeg, amLast;
+  __shared__ u32 vbase, g0InSeg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
-  if (tid == 0) { nQueued = 0; nVertexWords = 0; g0InSeg = 0; amLast = 0; }
+  if (tid == 0) { nQueued = 0; nVertexWords = 0; g0InSeg = 0; }
   __syncthreads();
   for (int i = tid; i < COUNT_WB; i += 256) {
     const size_t gi = w0 + i;
@@ -579,7 +627,7 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     cnt[i] = packed;
   }
   __syncthreads();
-  const int nq = nQueued;
+  const int nq = (MODE & 4) ? 0 : nQueued;
   u32 errBits = 0;
   for (int j = tid; j < nq; j += 256) {
     const int i = queue[j];
@@ -615,8 +663,9 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
   }
   __syncthreads();
+  if (MODE & 2) return;
   if (wv == 0) {
-    // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot, ticket
+    // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
     const u64 t = lane < COUNT_WB / 64 ? segTot[lane] : 0ull;
     const u64 incl = wave_inclusive_sum2(t);
     const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
@@ -624,67 +673,56 @@ __global__ __launch_bounds__(256) void k_count(const u64 *__restrict__ bits, con
     if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
     if (g0 > 0 && (g0 >> COUNT_LG) == blockIdx.x && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
       const u32 in = g0InSeg;
-      const u64 was = __hip_atomic_exchange(&tot->g0pre, excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32)),
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"((u32)was));                          // a returning atomic: its completion is waited for
+      tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
     }
-    if (lane == COUNT_WB / 64 - 1) {
-      const u64 was = __hip_atomic_exchange(&blockTot[blockIdx.x], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"((u32)was));
+    if (lane == COUNT_WB / 64 - 1) blockTot[blockIdx.x] = incl;
+  }
+}
+
+// Exclusive scan of the count blocks' totals (V | Q<<32 each) -> blockBase[2b], [2b+1] and the grand totals.  One
+// workgroup: rows of 1024 consecutive blocks, coalesced loads, ROWS rows in flight at once (the loads are what
+// takes time), then per row a workgroup-wide exclusive scan; V and Q of a row fit 32 bits each (1024 x 2^21),
+// the running bases are 64-bit.
+__global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blockTot, u64 *__restrict__ blockBase, u32 nblk,
+                                                     size_t g0, Totals *__restrict__ tot) {
+  constexpr int ROWS = 8;
+  __shared__ u64 waveSum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  u64 runV = 0, runQ = 0;
+  for (u32 base = 0; base < nblk; base += 1024 * ROWS) {
+    u64 v[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const u32 b = base + r * 1024 + tid;
+      v[r] = b < nblk ? blockTot[b] : 0ull;
     }
-    // the exchanges above have returned (their results are waited for) before any lane of this wave adds to the
-    // ticket: whoever sees the last ticket sees every block total
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      const u32 old = __hip_atomic_fetch_add(&tot->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      amLast = (old == gridDim.x - 1) ? 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      if (base + r * 1024 >= nblk) break;                          // workgroup-uniform
+      const u32 b = base + r * 1024 + tid;
+      const u64 incl = wave_inclusive_sum2(v[r]);
+      if (lane == 63) waveSum[wv] = incl;
+      __syncthreads();
+      u64 before = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) { const u64 t = waveSum[w]; all += t; if (w < wv) before += t; }
+      const u64 excl = before + incl - v[r];                       // halves stay below 2^32: no carry crosses
+      const u64 bV = runV + (excl & 0xffffffffull), bQ = runQ + (excl >> 32);
+      if (b < nblk) {
+        blockBase[2 * (size_t)b] = bV;
+        blockBase[2 * (size_t)b + 1] = bQ;
+        if (g0 > 0 && (g0 >> COUNT_LG) == b) {
+          const u64 in = tot->g0pre;
+          tot->V0 = bV + (in & 0xffffffffull);
+          tot->Q0 = bQ + (in >> 32);
+        }
+      }
+      runV += all & 0xffffffffull;
+      runQ += all >> 32;
+      __syncthreads();
     }
   }
-  __syncthreads();
-  if (!amLast) return;
-  // ---- the last block: scan of the block totals ----------------------------------------------------------------
-  const u32 nblk = gridDim.x;
-  const u32 per = (nblk + 255) / 256;
-  const u32 b0 = tid * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-  u64 sumV = 0, sumQ = 0;
-  for (u32 b = b0; b < b1; b++) {
-    const u64 t = __hip_atomic_load(&blockTot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sumV += t & 0xffffffffull;
-    sumQ += t >> 32;
-  }
-  // exclusive scan of the 256 partial sums (u64 each; V and Q separately through LDS)
-  u64 baseV, baseQ;
-  {
-    lastSum[tid] = sumV;
-    __syncthreads();
-    u64 acc = 0;
-    for (int i = 0; i < tid; i++) acc += lastSum[i];
-    baseV = acc;
-    u64 all = acc;
-    for (int i = tid; i < 256; i++) all += lastSum[i];
-    __syncthreads();
-    if (tid == 0) tot->totV = all;
-    lastSum[tid] = sumQ;
-    __syncthreads();
-    acc = 0;
-    for (int i = 0; i < tid; i++) acc += lastSum[i];
-    baseQ = acc;
-    all = acc;
-    for (int i = tid; i < 256; i++) all += lastSum[i];
-    if (tid == 0) tot->totQ = all;
-  }
-  for (u32 b = b0; b < b1; b++) {
-    const u64 t = __hip_atomic_load(&blockTot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    blockBase[2 * (size_t)b] = baseV;
-    blockBase[2 * (size_t)b + 1] = baseQ;
-    if (g0 > 0 && (g0 >> COUNT_LG) == b) {
-      const u64 in = __hip_atomic_load(&tot->g0pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tot->V0 = baseV + (in & 0xffffffffull);
-      tot->Q0 = baseQ + (in >> 32);
-    }
-    baseV += t & 0xffffffffull;
-    baseQ += t >> 32;
-  }
+  if (tid == 0) { tot->totV = runV; tot->totQ = runQ; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1641,8 +1679,10 @@ hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s) {
 
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
-  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot,
-                     w.blockBase, nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
+  hipLaunchKernelGGL(k_count<0>, dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot,
+                     nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
+  const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals);
   return hipGetLastError();
 }
 

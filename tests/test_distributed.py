@@ -111,3 +111,75 @@ def test_aliasing_check():
     occ2 = np.zeros(40, dtype=bool)
     occ2[5:30] = True
     assert D.aliasing_crosses_slabs(occ2, [(0, 20), (20, 40)]) == -1      # no gap, no aliasing
+
+
+def _fake_worker(rank, world, port, scenario, out_dir):
+    """ShardedExtractor.extract over gloo with a stand-in for the GPU extractor: what travels in the count all-gather."""
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from midas_journal_740_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nz, ny, nx = 40, 4, 6
+        calls = {}
+
+        def count(ptr, desc, params, slab):
+            calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
+            if scenario == "fail" and rank == 1:
+                raise pkg._abi.CuberilleError(pkg._abi.ERR_HALO, "synthetic failure")
+            return 100 + rank, 7 * (rank + 1)
+
+        def slab_info():
+            # (alias source below the buffer, lowest, highest occupied owned slice)
+            if scenario == "alias":
+                return (rank == 1, 0, 5 if rank == 0 else 30)
+            if scenario == "alias_nothing_below":
+                return (rank == 1, -1, -1 if rank == 0 else 30)
+            return (False, 0, nz - 1)
+
+        def emit(poff, coff):
+            calls["offsets"] = (poff, coff)
+            return types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
+        fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, result=None)
+        prm = pkg.make_params(0.5)
+        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm)
+        assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
+        buf = torch.zeros((sh.hi - sh.lo, ny, nx))
+        err = ""
+        try:
+            sh.extract(buf, prm)
+        except RuntimeError as e:
+            err = str(e)
+        # a longer walk than the halo was sized for is refused before anything is exchanged
+        too_far = ""
+        try:
+            sh.extract(buf, pkg.make_params(0.5, step=2.0))
+        except ValueError as e:
+            too_far = str(e)
+        assert "halo" in too_far
+        np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([err, repr(calls.get("offsets")), repr(calls.get("slab"))]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below"])
+def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
+    """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
+    (nobody is left waiting in the all-gather); quirk Q1 crossing the slab boundary is refused exactly when a rank
+    below holds an occupied slice."""
+    port = _free_port()
+    mp.spawn(_fake_worker, args=(2, port, scenario, str(tmp_path)), nprocs=2, join=True)
+    rows = [np.load(str(tmp_path / ("r%d.npy" % r))) for r in range(2)]
+    if scenario in ("ok", "alias_nothing_below"):
+        assert rows[0][0] == "" and rows[1][0] == ""
+        assert rows[0][1] == "(0, 0)" and rows[1][1] == "(100, 7)"
+        assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 12, 20, 40)"
+    elif scenario == "fail":
+        assert all("failed on rank(s) [1]" in r[0] for r in rows)
+    else:
+        assert all("quirk Q1" in r[0] and "below rank 1" in r[0] for r in rows)
