@@ -48,8 +48,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, totals, points, cells, cmap, headV, headQ, vqueue,
-      survivors, walkState;
+  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, totals, points, cells, cmap, headV, headQ, vqueue;
   Totals *hostTotals = nullptr;          // pinned
   hipEvent_t ev[8] = {};
   Tuning tune;                           // development switches (cuberille_debug_set_option)
@@ -182,8 +181,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (c->own) (void)hipStreamSynchronize(c->own);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
-                    &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->survivors,
-                    &c->walkState};
+                    &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   for (int i = 0; i < 2; i++) {
@@ -427,16 +425,6 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
     if (!w.vqueue && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess) w.headV = (u32 *)c->headV.p;
     (void)hipGetLastError();
   }
-  // projection: survivor list of the dense first phase (4 B + 8 B per vertex at most)
-  w.survivors = nullptr;
-  w.walkState = nullptr;
-  if (c->prm.project && c->tune.proj_phase_a && nV < 0xffffffffULL) {
-    if (c->survivors.reserve((size_t)(nV ? nV : 1) * sizeof(u32)) == hipSuccess &&
-        c->walkState.reserve((size_t)(nV ? nV : 1) * 2 * sizeof(float)) == hipSuccess) {
-      w.survivors = (u32 *)c->survivors.p;
-      w.walkState = (float *)c->walkState.p;
-    } else (void)hipGetLastError();
-  }
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
   HIP_TRY(c, launch_heads(w, c->g, c->tot.totV, c->tot.totQ, s));
@@ -593,8 +581,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(proj_phase_a)
-  OPT(proj_a_iters)
+  OPT(points_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal)
 #undef OPT
   return false;
 }

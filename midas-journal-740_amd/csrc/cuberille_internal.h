@@ -45,8 +45,7 @@ struct Totals {        // device-resident, zeroed before every count, mirrored t
   u64 g0pre;           // in-block prefix (V | Q << 32) at the first owned word, left by the count block that holds it
   u32 err;             // device-side error flags
   u32 nVertexWords;    // entries in the vertex-word queue (words that create at least one vertex)
-  u32 nSurvivors;      // projection: vertices the dense first phase handed on to the refilling walk
-  u32 pad_;
+  u32 pad_[2];
 };
 
 enum {
@@ -74,8 +73,6 @@ struct Workspace {     // device pointers valid for one count/emit pair
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
   u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
   u32 *vqueue;         // counted-range indices of the words that create vertices, in no particular order (or null)
-  u32 *survivors;      // projection: indices of the vertices still walking after the dense first phase (or null)
-  float *walkState;    // projection: per survivor, step length and loop counter carried over (2 x 4 B)
 };
 
 // Development switches, set per context through cuberille_debug_set_option (never read from the environment).
@@ -86,8 +83,6 @@ struct Tuning {
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
-  int proj_phase_a = 1;       // dense in-cell first phase before the refilling walk (0 = refilling walk only)
-  int proj_a_iters = 0;       // iterations of the dense phase (0 = default)
 };
 
 struct Params {

@@ -18,10 +18,9 @@
 //              vertex; cells: one lane per output quad, located by a per-wave search of the prefix
 //              arrays, ids staged through LDS; everything lands at its final, reference-order index;
 //              corner ids through a dense lattice-corner map
-//   project  : phase A, one lane per vertex, walks while the vertex stays in its start cell (dense waves,
-//              one gather); phase B, refilling waves, carries the survivors on; the gradient image is
-//              evaluated on the fly (never materialised); runs between the point and the cell pass so that
-//              the shorter-diagonal triangle split is fused into the cell pass.
+//   project  : refilling waves, the damped gradient walk with the gradient image evaluated on the
+//              fly (never materialised); runs between the point and the cell pass so that the
+//              shorter-diagonal triangle split is fused into the cell pass.
 // Bit-exactness of the floating-point part against the CPU oracle relies on
 // -ffp-contract=off (no FMA fusion; the explicit fma calls in the walk are the compiler's own f64
 // sqrt / division sequences written out) and IEEE f64 arithmetic; see csrc/Makefile.

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Same-box A/B of per-context development switches (cuberille_debug_set_option) on a bench workload:
+   python profiles/ablate.py [--workload marschner_lobb --size 1024] name=v1,v2,... [name2=...]
+Every combination is run `--reps` times on the resident volume; prints the median stage times."""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="marschner_lobb")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("sweeps", nargs="*")
+    args = ap.parse_args()
+    import torch
+    pkg = graft.load_package()
+    dev = torch.device("cuda", 0)
+    n = args.size
+    dtype, iso, thr = bench.WORKLOADS[args.workload]
+    vol = bench.generate_block(pkg, torch, args.workload, n, 0, n, None, dev)
+    torch.cuda.synchronize()
+    ex = pkg.Extractor(0)
+    desc = pkg.make_desc(dtype, (n, n, n))
+    prm = pkg.make_params(iso, triangles=True, project=True, threshold=thr, step=0.25, relax=0.95, max_steps=50)
+    names, values = [], []
+    for sw in args.sweeps:
+        k, v = sw.split("=")
+        names.append(k)
+        values.append([int(x) for x in v.split(",")])
+    keys = ["ms_classify", "ms_count", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
+    for combo in itertools.product(*values) if names else [()]:
+        ex.debug_option("defaults", 0)
+        for k, v in zip(names, combo):
+            ex.debug_option(k, v)
+        rows = []
+        for _ in range(args.reps + 2):
+            r = ex.extract_device(vol.data_ptr(), desc, prm)
+            rows.append([getattr(r, k) for k in keys])
+        med = np.median(np.array(rows[2:]), axis=0)
+        print(" ".join("%s=%d" % kv for kv in zip(names, combo)) or "defaults",
+              " ".join("%s %.4f" % (k[3:], m) for k, m in zip(keys, med)),
+              "iters", r.proj_iterations, flush=True)
+
+
+if __name__ == "__main__":
+    main()

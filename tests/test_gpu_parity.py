@@ -347,18 +347,18 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
 
 
 @pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"),
-                                     ("no_cmap", "no_heads", "no_vqueue"), ("proj_phase_a",), ("classify_variant",)])
+                                     ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",)])
 def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, options):
     """When the dense corner map (4 B per lattice corner), the head tables or the vertex-word queue cannot be
-    allocated the kernels recompute ids / search the prefix arrays instead; the projection also runs without its
-    dense first phase and the sweep without its staged spans; same mesh every way.  The switches are per-context
+    allocated the kernels recompute ids / search the prefix arrays instead; the sweep also runs without its staged
+    spans; same mesh every way.  The switches are per-context
     options of the C ABI (cuberille_debug_set_option), not environment variables."""
     rng = np.random.default_rng(11)
     vox = rng.integers(0, 255, size=(9, 10, 130), dtype=np.uint8)
     vox[4] = 0                                    # an empty slice: exercises the aliasing redirect too
     try:
         for o in options:
-            extractor.debug_option(o, 0 if o == "proj_phase_a" else 1)
+            extractor.debug_option(o, 1)
         for vol, iso in [(volumes("nucleon.mha"), 128), (volumes("silicium.mha"), 85), (pkg.Volume(vox), 128)]:
             for tri in (0, 1):
                 kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
@@ -783,3 +783,146 @@ def test_caller_stream_orders_the_extraction(pkg, oracle, extractor, volumes):
     torch.cuda.synchronize()
     extractor.extract_device(dev.data_ptr(), desc, prm)
     assert_same_mesh(extractor.download(), want)
+
+
+def _bench_field(pkg, field, n):
+    if field == "sphere_sdf":
+        return pkg.volumes.sphere_sdf(n)
+    if field == "gradient_noise":
+        return pkg.volumes.gradient_noise(n, n, n * 1000000, 0, n)
+    raise ValueError(field)
+
+
+def test_bench_fields_match_oracle_and_frozen_digests(pkg, oracle, extractor):
+    """The bench's own generators at sizes the oracle finishes in seconds, with the bench's parameters: smooth float32
+    fields whose walks take many in-cell iterations and change cells often -- the regime of the headline number.
+    sphere_sdf 64^3 / 128^3 (thr 0.05) and uint8 gradient_noise 128^3 (iso 128): ids, order, float bits and the number
+    of passes through the walk loop equal the oracle's, and the bytes equal the committed digests
+    (tests/golden/bench_field_digests.json, bit-portable generators)."""
+    import hashlib
+    rows = json.load(open(os.path.join(GOLDEN, "bench_field_digests.json")))
+    assert len(rows) == 6
+    for r in rows:
+        vox = _bench_field(pkg, r["field"], r["n"])
+        assert hashlib.sha256(np.ascontiguousarray(vox).tobytes()).hexdigest() == r["volume_sha256"]
+        kw = dict(triangles=r["triangles"], project=r["project"], threshold=r["threshold"], step=r["step"], relax=r["relax"],
+                  max_steps=r["max_steps"])
+        mesh = run_gpu(pkg, extractor, pkg.Volume(vox), r["iso"], **kw)
+        ref = oracle.run(vox, r["iso"], **kw)
+        assert_same_mesh(mesh, ref)
+        assert int(extractor.result.proj_iterations) == ref.info["proj_iterations"] == r["proj_iterations"]
+        assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (r["points"], r["cells"])
+        assert hashlib.sha256(_point_bytes(mesh.points)).hexdigest() == r["points_sha256"], r
+        assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
+
+
+@pytest.mark.parametrize("n", [96, 128])
+def test_marschner_lobb_bench_field_matches_oracle(pkg, oracle, extractor, n):
+    """BASELINE.json configs[3]'s field (the headline workload) at 96^3 / 128^3 with the bench's parameters -- iso 0.5,
+    thr 0.002, step 0.25, relax 0.95, 50 steps: long walks, ~28 % of the vertices on the zero shell -- against the
+    oracle: ids, order, float bits, loop passes; whole, period-stacked (the weak-scaling volume) and cut into Z-slabs
+    with the halo the library asks for.  (sin/cos are not bit-portable: whoever generates the field hands the same
+    bytes to both sides; no frozen digest.)"""
+    import torch
+    kw = dict(triangles=1, project=1, threshold=0.002, step=0.25, relax=0.95, max_steps=50)
+    prm = pkg.make_params(0.5, **kw)
+    for vox in (pkg.volumes.marschner_lobb(n), pkg.volumes.marschner_lobb(n, 0, 2 * n, period=n)):
+        ref = oracle.run(vox, 0.5, **kw)
+        mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 0.5, **kw)
+        assert_same_mesh(mesh, ref)
+        assert int(extractor.result.proj_iterations) == ref.info["proj_iterations"]
+        assert len(ref.points) > 20000
+        nz = vox.shape[0]
+        halo = max(pkg.required_halo(pkg.make_desc(np.float32, (n, n, nz)), prm))
+        assert halo == 8
+        dev = torch.from_numpy(vox).cuda()
+        # the stacked volume has a run of empty slices between its two copies (the upper part of the field is outside,
+        # then two zero shells): quirk Q1 re-uses vertices across it, which slabs reproduce when the cuts leave the run
+        # and the occupied slice below it inside one slab
+        occupied = np.nonzero((vox >= 0.5).any(axis=(1, 2)))[0]
+        first_gap = int(occupied[np.nonzero(np.diff(occupied) > 1)[0][0]]) if (np.diff(occupied) > 1).any() else nz
+        c1 = min(nz // 3, first_gap // 2)
+        cuts = [0, c1, c1 + 9, nz]
+        pts, cells, poff, iters = [], [], 0, 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            lo, hi = max(a - halo, 0), min(b + halo, nz)
+            slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
+            n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi - lo)), prm, slab)
+            assert not extractor.slab_info()[0]
+            res = extractor.emit(poff, 0)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+            iters += int(res.proj_iterations)
+        assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+        assert iters == ref.info["proj_iterations"]
+        if first_gap < nz:
+            # a slab whose buffer starts inside the empty run cannot know what lies below: the count says so (the
+            # multi-GPU driver resolves it with the other ranks' occupancy) instead of silently skipping the re-use
+            a = first_gap + 12
+            slab = pkg._abi.Slab(nz, a - halo, a, nz, 0, 0)
+            extractor.count(dev[a - halo:].data_ptr(), pkg.make_desc(np.float32, (n, n, nz - a + halo)), prm, slab)
+            below, lowest, highest = extractor.slab_info()
+            assert below and lowest > first_gap and highest == int(occupied[-1])
+
+
+def test_slab_halo_is_sized_by_the_parameters(pkg, oracle, extractor):
+    """A slab must hold what the projection can reach: thin z spacing and a longer step need more than the 8 slices
+    of the defaults.  The library says how many (cuberille_required_halo), refuses less (CUBERILLE_ERR_HALO instead
+    of silently clamping the walk at the buffer edge), and with that halo the slabs reproduce the one-shot mesh."""
+    import torch
+    vox = pkg.volumes.sphere_sdf(72)
+    spacing = (1.0, 1.0, 0.25)
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.4, relax=0.97, max_steps=60)
+    prm = pkg.make_params(0.0, **kw)
+    ref = oracle.run(vox, 0.0, spacing=spacing, **kw)
+    nz, n = vox.shape[0], vox.shape[2]
+    halo = max(pkg.required_halo(pkg.make_desc(np.float32, (n, n, nz), spacing), prm))
+    assert halo > 30
+    dev = torch.from_numpy(vox).cuda()
+    a, b = 0, 36
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        hi = b + 8
+        extractor.count(dev[:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi), spacing), prm, pkg._abi.Slab(nz, 0, a, b, 0, 0))
+    assert e.value.code == pkg._abi.ERR_HALO and "cuberille_required_halo" in str(e.value)
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 36), (36, 72)]:
+        lo, hi = max(a - halo, 0), min(b + halo, nz)
+        slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
+        n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi - lo), spacing), prm, slab)
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def test_extract_host_overlapped_upload_equals_resident_volume(pkg, extractor):
+    """cuberille_extract_host on a volume large enough for the chunked, overlapped upload (pinned double buffer,
+    staging threads, every chunk thresholded while the next one crosses the link) gives bit for bit the mesh of
+    cuberille_extract_device on the same bytes already resident in HBM."""
+    import torch
+    n = 384                                               # 226 MB of float32: seven 32 MiB chunks
+    vox = pkg.volumes.sphere_sdf(n)
+    prm = pkg.make_params(0.0, triangles=True, project=True, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
+    extractor.extract_host(pkg.Volume(vox), prm)
+    a = extractor.download()
+    dev = torch.from_numpy(vox).cuda()
+    torch.cuda.synchronize()
+    extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.float32, (n, n, n)), prm)
+    b = extractor.download()
+    assert a.points.shape[0] > 400000
+    assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))
+    # uint8, ragged rows (not whole 64-voxel words): the chunked path must hand every z-range to the ragged sweep
+    rng = np.random.default_rng(5)
+    vox8 = pkg.volumes.gradient_noise(500, 500, 600, 0, 600)
+    prm8 = pkg.make_params(128, triangles=False, project=True)
+    extractor.extract_host(pkg.Volume(vox8), prm8)
+    a = extractor.download()
+    dev = torch.from_numpy(vox8).cuda()
+    torch.cuda.synchronize()
+    extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.uint8, (500, 500, 600)), prm8)
+    b = extractor.download()
+    assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))

@@ -160,3 +160,25 @@ def test_oracle_reproduces_committed_mesh_digests(pkg, oracle, volumes):
         assert (m.points.shape[0], m.cells.shape[0]) == (r["points"], r["cells"]), r["input"]
         assert hashlib.sha256(_point_bytes(m.points)).hexdigest() == r["points_sha256"], r["input"]
         assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
+
+
+def test_oracle_reproduces_bench_field_digests(pkg, oracle):
+    """tests/golden/bench_field_digests.json (made by make_bench_field_digests.py): the oracle on the bench's own
+    bit-portable fields is frozen too, so the checker of the GPU parity tests on those fields cannot drift."""
+    import hashlib
+    import json
+    from conftest import GOLDEN, point_bytes
+    rows = json.load(open(os.path.join(GOLDEN, "bench_field_digests.json")))
+    for r in rows:
+        if r["n"] > 64 and r["field"] == "sphere_sdf":
+            continue                                   # one size per field keeps the CPU suite short
+        if r["field"] == "sphere_sdf":
+            vox = pkg.volumes.sphere_sdf(r["n"])
+        else:
+            vox = pkg.volumes.gradient_noise(r["n"], r["n"], r["n"] * 1000000, 0, r["n"])
+        assert hashlib.sha256(np.ascontiguousarray(vox).tobytes()).hexdigest() == r["volume_sha256"]
+        m = oracle.run(vox, r["iso"], triangles=r["triangles"], project=r["project"], threshold=r["threshold"], step=r["step"],
+                       relax=r["relax"], max_steps=r["max_steps"])
+        assert (len(m.points), len(m.cells), m.info["proj_iterations"]) == (r["points"], r["cells"], r["proj_iterations"])
+        assert hashlib.sha256(point_bytes(m.points)).hexdigest() == r["points_sha256"]
+        assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"]
