@@ -182,6 +182,9 @@ int cuberille_slice_occupancy(cuberille_ctx *ctx, uint32_t *occupied, size_t n_s
  * path): name = a field of cuberille::Tuning (csrc/cuberille_internal.h), or "defaults" to reset them all.
  * Results never depend on them, only speed and memory.  Used by the parity tests and the ablation scripts. */
 int cuberille_debug_set_option(cuberille_ctx *ctx, const char *name, int64_t value);
+/* Measurement aid for the PCIe-inclusive numbers: seconds this context's device takes to receive `bytes` from
+ * pinned host memory (64 MiB copies back to back on one stream) -- the link rate cuberille_extract_host is held to. */
+int cuberille_debug_h2d_seconds(cuberille_ctx *ctx, size_t bytes, double *seconds);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ EXPORTS = [
     "cuberille_destroy", "cuberille_set_stream", "cuberille_extract_host", "cuberille_extract_device",
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
-    "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option",
+    "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
 ]
 ABI_VERSION = 4
 
@@ -116,6 +116,7 @@ def lib():
     L.cuberille_required_halo.argtypes = [C.POINTER(ImageDesc), C.POINTER(Params), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.cuberille_slab_info.argtypes = [vp, C.POINTER(SlabStatus)]
     L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.cuberille_debug_h2d_seconds.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double)]
     _lib = L
     return L
 

@@ -130,7 +130,14 @@ public:
    *  callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
    *  polydata itk::VTKPolyDataWriter would give for GetOutput(), straight from the device buffers. */
   itkGetMacro(LastMeshFillSeconds, double);
+  /** Wall time of the last update's cuberille_extract_host call (upload overlapped with the sweep, then the rest
+   * of the extraction) and of copying the flat mesh buffers back to the host. */
+  itkGetMacro(LastExtractSeconds, double);
+  itkGetMacro(LastDownloadSeconds, double);
   void WriteLastMeshAsVTKPolyData(const char *fileName, int threads = 0);
+  /** Not in the reference: seconds the device of this filter takes to receive `bytes` from pinned host memory
+   *  (cuberille_debug_h2d_seconds) -- what the upload inside Update() is measured against. */
+  double MeasureHostToDeviceSeconds(unsigned long long bytes);
 
 protected:
   CuberilleImageToMeshFilter();
@@ -156,6 +163,8 @@ private:
   int m_Device;
   double m_LastDeviceSeconds;
   double m_LastMeshFillSeconds;
+  double m_LastExtractSeconds;
+  double m_LastDownloadSeconds;
   ::cuberille_ctx    *m_Context;
 };
 

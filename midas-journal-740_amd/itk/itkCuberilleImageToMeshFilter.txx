@@ -8,8 +8,14 @@
 #include "itkCuberilleImageToMeshFilter.h"
 #include "cuberille_hip.h"
 
+#include <cstdlib>
 #include <ctime>
+#include <new>
 #include <vector>
+#if __cplusplus >= 201103L
+#include <chrono>
+#include <thread>
+#endif
 
 namespace itk
 {
@@ -26,6 +32,67 @@ template <> struct PixelCode<unsigned int>   { enum { Value = CUBERILLE_PIX_U32 
 template <> struct PixelCode<int>            { enum { Value = CUBERILLE_PIX_I32 }; };
 template <> struct PixelCode<float>          { enum { Value = CUBERILLE_PIX_F32 }; };
 template <> struct PixelCode<double>         { enum { Value = CUBERILLE_PIX_F64 }; };
+
+inline double WallSeconds()
+{
+#if __cplusplus >= 201103L
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#else
+  return static_cast<double>(std::clock()) / CLOCKS_PER_SEC;
+#endif
+}
+
+// f(i) for the ranges [i0, i1) of a few host threads (the mesh fill is a plain copy into independent elements)
+template <class F> void ParallelRanges(uint64_t n, F f)
+{
+#if __cplusplus >= 201103L
+  unsigned int hw = std::thread::hardware_concurrency();
+  const unsigned int nT = n < 65536 ? 1u : (hw >= 16 ? 8u : (hw >= 2 ? hw / 2 : 1u));
+  if (nT > 1)
+    {
+    std::vector<std::thread> th;
+    for (unsigned int t = 0; t < nT; t++) th.push_back(std::thread(f, n * t / nT, n * (t + 1) / nT));
+    for (unsigned int t = 0; t < nT; t++) th[t].join();
+    return;
+    }
+#endif
+  f(static_cast<uint64_t>(0), n);
+}
+
+#ifdef ITK_LITE
+template <class TCell> void ReleaseCellSlab(void *slab) { ::operator delete(slab); }   // the shim's cells hold ids only
+
+// Bulk form of the loop at txx:309-329 for the ITK-lite mesh: the cells of the whole mesh are constructed in ONE
+// array, which the mesh adopts (it owns and frees its cells, as a whole); the cell container holds pointers into it.
+template <class TMesh, class TCell, unsigned int K>
+void BulkFillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells)
+{
+  typedef typename TMesh::CellType BaseCellType;
+  typedef typename TMesh::PointIdentifier PointIdentifier;
+  TCell *slab = static_cast<TCell *>(::operator new(sizeof(TCell) * (nCells ? nCells : 1)));
+  std::vector<BaseCellType *> &container = mesh->GetCells()->CastToSTLContainer();
+  container.resize(static_cast<size_t>(nCells));
+  BaseCellType **slots = nCells ? &container[0] : 0;
+  struct Fill
+    {
+    TCell *slab; BaseCellType **slots; const uint64_t *ids;
+    void operator()(uint64_t c0, uint64_t c1) const
+      {
+      PointIdentifier v[K];
+      for (uint64_t c = c0; c < c1; c++)
+        {
+        TCell *cell = new (slab + c) TCell;
+        for (unsigned int k = 0; k < K; k++) v[k] = static_cast<PointIdentifier>(ids[K * c + k]);
+        cell->SetPointIds(v);
+        slots[c] = cell;
+        }
+      }
+    } fill = {slab, slots, ids};
+  ParallelRanges(nCells, fill);
+  mesh->SetCellsAllocationMethod(TMesh::CellsAllocatedAsStaticArray);
+  mesh->AdoptCellArray(slab, &ReleaseCellSlab<TCell>);
+}
+#endif
 
 // the one interpolator the kernels implement (I5: linear, double coordinates)
 template <class TInterpolator, class TImage> struct IsGpuInterpolator { enum { Value = 0 }; };
@@ -47,6 +114,8 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_Device = 0;
   m_LastDeviceSeconds = 0.0;
   m_LastMeshFillSeconds = 0.0;
+  m_LastExtractSeconds = 0.0;
+  m_LastDownloadSeconds = 0.0;
   m_Context = 0;
 }
 
@@ -109,25 +178,45 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));
   cuberille_result res;
+  const double extractStart = cuberille_detail::WallSeconds();
   if (cuberille_extract_host(m_Context, &desc, image->GetBufferPointer(), &prm, &res) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_extract_host: " << cuberille_last_error(m_Context));
   m_LastDeviceSeconds = 1e-3 * res.ms_total;
 
-  std::vector<float> points(res.n_points * 3 + 1);
-  std::vector<uint64_t> cells(res.n_cells * res.verts_per_cell + 1);
-  if (cuberille_mesh_download(m_Context, &points[0], &cells[0]) != CUBERILLE_OK)
-    itkExceptionMacro(<< "cuberille_mesh_download: " << cuberille_last_error(m_Context));
+  m_LastExtractSeconds = cuberille_detail::WallSeconds() - extractStart;
 
-  const std::clock_t fillStart = std::clock();
-  // pour the flat buffers into the mesh the way the reference does element by element: points by
-  // value, one heap cell per face handed to the mesh, which owns it from then on
-  if (res.n_points) mesh->GetPoints()->Reserve(static_cast<PointIdentifier>(res.n_points));
-  PointType p;
-  for (uint64_t i = 0; i < res.n_points; i++)
+  // flat buffers (uninitialised: every element is written by the download)
+  const double downloadStart = cuberille_detail::WallSeconds();
+  float *points = static_cast<float *>(std::malloc(sizeof(float) * (res.n_points * 3 + 1)));
+  uint64_t *cells = static_cast<uint64_t *>(std::malloc(sizeof(uint64_t) * (res.n_cells * res.verts_per_cell + 1)));
+  if (!points || !cells) { std::free(points); std::free(cells); itkExceptionMacro(<< "out of host memory for the mesh buffers"); }
+  if (cuberille_mesh_download(m_Context, points, cells) != CUBERILLE_OK)
     {
-    p[0] = points[3 * i]; p[1] = points[3 * i + 1]; p[2] = points[3 * i + 2];
-    mesh->GetPoints()->InsertElement(static_cast<PointIdentifier>(i), p);
+    std::free(points); std::free(cells);
+    itkExceptionMacro(<< "cuberille_mesh_download: " << cuberille_last_error(m_Context));
     }
+  m_LastDownloadSeconds = cuberille_detail::WallSeconds() - downloadStart;
+
+  const double fillStart = cuberille_detail::WallSeconds();
+  // points by value, straight into the container's elements
+  {
+    std::vector<PointType> &pc = mesh->GetPoints()->CastToSTLContainer();
+    pc.resize(static_cast<size_t>(res.n_points));
+    struct FillPoints
+      {
+      PointType *dst; const float *src;
+      void operator()(uint64_t i0, uint64_t i1) const
+        { for (uint64_t i = i0; i < i1; i++) { dst[i][0] = src[3 * i]; dst[i][1] = src[3 * i + 1]; dst[i][2] = src[3 * i + 2]; } }
+      } fp = {res.n_points ? &pc[0] : 0, points};
+    cuberille_detail::ParallelRanges(res.n_points, fp);
+  }
+#ifdef ITK_LITE
+  // ITK-lite mesh: all cells in one array that the mesh adopts and frees as a whole
+  if (res.verts_per_cell == 3) cuberille_detail::BulkFillCells<OutputMeshType, TriangleCellType, 3>(mesh.GetPointer(), cells, res.n_cells);
+  else cuberille_detail::BulkFillCells<OutputMeshType, QuadrilateralCellType, 4>(mesh.GetPointer(), cells, res.n_cells);
+#else
+  // real ITK: one heap cell per face handed to the mesh, which owns it from then on, exactly as the reference
+  // does (txx:309-329) -- itk::Mesh frees CellsAllocatedDynamicallyCellByCell cells one by one
   if (res.verts_per_cell == 3)
     {
     PointIdentifier ids[3];
@@ -152,7 +241,10 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
       mesh->SetCell(static_cast<CellIdentifier>(c), cell);
       }
     }
-  m_LastMeshFillSeconds = static_cast<double>(std::clock() - fillStart) / CLOCKS_PER_SEC;
+#endif
+  std::free(points);
+  std::free(cells);
+  m_LastMeshFillSeconds = cuberille_detail::WallSeconds() - fillStart;
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>
@@ -161,6 +253,17 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::WriteL
   if (!m_Context) itkExceptionMacro(<< "WriteLastMeshAsVTKPolyData: no Update() has run on this filter");
   if (cuberille_mesh_write_vtk(m_Context, fileName, threads) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_mesh_write_vtk: " << cuberille_last_error(m_Context));
+}
+
+template <class TInputImage, class TOutputMesh, class TInterpolator>
+double CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::MeasureHostToDeviceSeconds(unsigned long long bytes)
+{
+  if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
+    itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));
+  double s = 0.0;
+  if (cuberille_debug_h2d_seconds(m_Context, static_cast<size_t>(bytes), &s) != CUBERILLE_OK)
+    itkExceptionMacro(<< "cuberille_debug_h2d_seconds: " << cuberille_last_error(m_Context));
+  return s;
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>

@@ -514,10 +514,24 @@ public:
   unsigned long GetNumberOfCells() const { return m_Cells.IsNull() ? 0 : m_Cells->Size(); }
   void SetPoint(PointIdentifier id, const PointType &p) { GetPoints()->InsertElement(id, p); }
   bool GetPoint(PointIdentifier id, PointType *p) const { if (m_Points.IsNull() || id >= m_Points->Size()) return false; *p = m_Points->GetElement(id); return true; }
+  // How the cell objects were allocated, hence who frees them (names and meaning of itk::Mesh):
+  //   CellsAllocatedDynamicallyCellByCell  each cell came from its own `new` and the mesh deletes it (txx:310-313);
+  //   CellsAllocatedAsStaticArray          the cells live in storage the mesh does not free cell by cell.
+  // ITK-lite addition: AdoptCellArray hands such an array TO the mesh, which releases it as a whole (one call) when it
+  // is re-initialised or destroyed -- the bulk fill of the MI355X filter uses it, so the mesh still owns its cells.
+  enum CellsAllocationMethodType { CellsAllocationMethodUndefined, CellsAllocatedAsStaticArray,
+                                   CellsAllocatedAsADynamicArray, CellsAllocatedDynamicallyCellByCell };
+  void SetCellsAllocationMethod(CellsAllocationMethodType m) { m_CellsAllocationMethod = m; }
+  CellsAllocationMethodType GetCellsAllocationMethod() const { return m_CellsAllocationMethod; }
+  void AdoptCellArray(void *array, void (*release)(void *)) {
+    ReleaseCellArray();
+    m_CellArray = array;
+    m_ReleaseCellArray = release;
+  }
   // the mesh takes over the cell object and deletes it later (ITK ownership rule, txx:310-313)
   void SetCell(CellIdentifier id, CellAutoPointer &cell) {
     CellsContainer *c = GetCells();
-    if (id < c->Size() && c->ElementAt(id)) delete c->ElementAt(id);
+    if (m_CellsAllocationMethod != CellsAllocatedAsStaticArray && id < c->Size() && c->ElementAt(id)) delete c->ElementAt(id);
     c->InsertElement(id, cell.ReleaseOwnership());
   }
   bool GetCell(CellIdentifier id, CellAutoPointer &cell) const {
@@ -526,14 +540,28 @@ public:
     return true;
   }
   virtual void Initialize() {
-    if (m_Cells.IsNotNull()) { for (CellIdentifier i = 0; i < m_Cells->Size(); i++) delete m_Cells->ElementAt(i); m_Cells->Initialize(); }
+    if (m_Cells.IsNotNull()) {
+      if (m_CellsAllocationMethod != CellsAllocatedAsStaticArray)
+        for (CellIdentifier i = 0; i < m_Cells->Size(); i++) delete m_Cells->ElementAt(i);
+      m_Cells->Initialize();
+    }
+    ReleaseCellArray();
+    m_CellsAllocationMethod = CellsAllocatedDynamicallyCellByCell;
     if (m_Points.IsNotNull()) m_Points->Initialize();
   }
 protected:
-  Mesh() {}
+  Mesh() : m_CellsAllocationMethod(CellsAllocatedDynamicallyCellByCell), m_CellArray(0), m_ReleaseCellArray(0) {}
   ~Mesh() { Initialize(); }
+  void ReleaseCellArray() {
+    if (m_CellArray && m_ReleaseCellArray) m_ReleaseCellArray(m_CellArray);
+    m_CellArray = 0;
+    m_ReleaseCellArray = 0;
+  }
   PointsContainerPointer m_Points;
   CellsContainerPointer m_Cells;
+  CellsAllocationMethodType m_CellsAllocationMethod;
+  void *m_CellArray;
+  void (*m_ReleaseCellArray)(void *);
 };
 
 // declared so that the driver's typedefs and includes resolve; never instantiated

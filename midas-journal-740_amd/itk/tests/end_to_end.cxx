@@ -79,6 +79,8 @@ int main(int argc, char *argv[])
     filter->Update();
     const double tUpdate = now() - t0;
     MeshType::Pointer mesh = filter->GetOutput();
+    const double volumeBytes = static_cast<double>(n) * n * n * sizeof(float);
+    const double linkSeconds = filter->MeasureHostToDeviceSeconds(static_cast<unsigned long long>(volumeBytes));
 
     typedef itk::VTKPolyDataWriter<MeshType> WriterType;
     WriterType::Pointer writer = WriterType::New();
@@ -94,8 +96,11 @@ int main(int argc, char *argv[])
 
     std::cout << "{\"n\": " << n << ", \"points\": " << mesh->GetNumberOfPoints() << ", \"cells\": "
               << mesh->GetNumberOfCells() << ", \"first_update_s\": " << tFirst << ", \"update_s\": " << tUpdate
-              << ", \"device_s\": " << filter->GetLastDeviceSeconds() << ", \"mesh_fill_s\": "
-              << filter->GetLastMeshFillSeconds() << ", \"itk_writer_s\": " << tWriter << ", \"flat_writer_s\": " << tFlat
+              << ", \"device_s\": " << filter->GetLastDeviceSeconds() << ", \"upload_extract_s\": "
+              << filter->GetLastExtractSeconds() << ", \"download_s\": " << filter->GetLastDownloadSeconds()
+              << ", \"mesh_fill_s\": " << filter->GetLastMeshFillSeconds() << ", \"itk_writer_s\": " << tWriter << ", \"flat_writer_s\": " << tFlat
+              << ", \"volume_bytes\": " << volumeBytes << ", \"pinned_h2d_s\": " << linkSeconds
+              << ", \"pinned_h2d_GBps\": " << volumeBytes / linkSeconds * 1e-9
               << ", \"same_bytes\": " << (same ? "true" : "false") << "}" << std::endl;
     return same ? 0 : 1;
     }

@@ -904,7 +904,7 @@ def test_extract_host_overlapped_upload_equals_resident_volume(pkg, extractor):
     staging threads, every chunk thresholded while the next one crosses the link) gives bit for bit the mesh of
     cuberille_extract_device on the same bytes already resident in HBM."""
     import torch
-    n = 384                                               # 226 MB of float32: seven 32 MiB chunks
+    n = 656                                               # 1.13 GB of float32: thirty-four 32 MiB chunks
     vox = pkg.volumes.sphere_sdf(n)
     prm = pkg.make_params(0.0, triangles=True, project=True, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
     extractor.extract_host(pkg.Volume(vox), prm)
@@ -913,16 +913,18 @@ def test_extract_host_overlapped_upload_equals_resident_volume(pkg, extractor):
     torch.cuda.synchronize()
     extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.float32, (n, n, n)), prm)
     b = extractor.download()
-    assert a.points.shape[0] > 400000
+    assert a.points.shape[0] > 1200000
     assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))
-    # uint8, ragged rows (not whole 64-voxel words): the chunked path must hand every z-range to the ragged sweep
-    rng = np.random.default_rng(5)
-    vox8 = pkg.volumes.gradient_noise(500, 500, 600, 0, 600)
-    prm8 = pkg.make_params(128, triangles=False, project=True)
-    extractor.extract_host(pkg.Volume(vox8), prm8)
+    del dev, vox
+    # uint16, ragged rows (not whole 64-voxel words): the chunked path must hand every z-range to the ragged sweep
+    vox16 = np.concatenate([pkg.volumes.gradient_noise(1000, 700, 800, z, z + 32) for z in range(0, 800, 32)])
+    vox16 = vox16.astype(np.uint16) * np.uint16(7)
+    prm16 = pkg.make_params(7 * 128, triangles=False, project=True)
+    extractor.extract_host(pkg.Volume(vox16), prm16)
     a = extractor.download()
-    dev = torch.from_numpy(vox8).cuda()
+    dev = torch.from_numpy(vox16.view(np.int16)).cuda()
     torch.cuda.synchronize()
-    extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.uint8, (500, 500, 600)), prm8)
+    extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.uint16, (1000, 700, 800)), prm16)
     b = extractor.download()
+    assert a.points.shape[0] > 1000000
     assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     pkg._abi.build()
     lib = pkg._abi.lib()
     header = open(os.path.join(ROOT, "include", "cuberille_hip.h")).read()
-    declared = set(re.findall(r"\b(cuberille_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(cuberille_[a-z_0-9]+)\s*\(", header))
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
