@@ -8,6 +8,7 @@
 #include "itkCuberilleImageToMeshFilter.h"
 #include "cuberille_hip.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <ctime>
 #include <new>
@@ -94,6 +95,185 @@ void BulkFillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells)
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// Host projection for interpolators the kernels do not implement (TInterpolator other than
+// LinearInterpolateImageFunction<TInputImage,double>).  The GPU still does the whole topology -- inside test, faces,
+// vertex ids and order, lattice points -- and hands back unprojected quads; this walks every vertex as txx:439-474
+// does, calling the USER'S interpolator for the value (txx:455), and splits the quads afterwards (txx:286-321).
+// The gradient is what txx:478-498 sets up: GradientImageFilter (central differences in float, image spacing,
+// direction applied) read through a vector linear interpolator; restated here on the image buffer so that no
+// gradient image is materialised.
+// ---------------------------------------------------------------------------------------------------------------
+template <class TImage> class HostGradient
+{
+public:
+  typedef typename TImage::PixelType PixelType;
+  explicit HostGradient(const TImage *image)
+  {
+    const typename TImage::RegionType region = image->GetBufferedRegion();
+    typename TImage::PointType first;
+    image->TransformIndexToPhysicalPoint(region.GetIndex(), first);
+    m_Buffer = image->GetBufferPointer();
+    double i2p[9];
+    for (int r = 0; r < 3; r++)
+      {
+      m_N[r] = static_cast<long>(region.GetSize()[r]);
+      m_Origin[r] = first[r];
+      m_Coef[r] = static_cast<float>(0.5 * (1.0 / image->GetSpacing()[r]));
+      for (int c = 0; c < 3; c++)
+        {
+        m_Dir[r * 3 + c] = image->GetDirection()[r][c];
+        i2p[r * 3 + c] = m_Dir[r * 3 + c] * image->GetSpacing()[c];
+        }
+      }
+    // PhysicalPointToIndex = inverse of Direction * diag(spacing), by cofactors
+    const double c00 = i2p[4] * i2p[8] - i2p[5] * i2p[7], c01 = i2p[5] * i2p[6] - i2p[3] * i2p[8];
+    const double c02 = i2p[3] * i2p[7] - i2p[4] * i2p[6];
+    const double det = i2p[0] * c00 + i2p[1] * c01 + i2p[2] * c02;
+    m_P2I[0] = c00 / det; m_P2I[1] = (i2p[2] * i2p[7] - i2p[1] * i2p[8]) / det; m_P2I[2] = (i2p[1] * i2p[5] - i2p[2] * i2p[4]) / det;
+    m_P2I[3] = c01 / det; m_P2I[4] = (i2p[0] * i2p[8] - i2p[2] * i2p[6]) / det; m_P2I[5] = (i2p[2] * i2p[3] - i2p[0] * i2p[5]) / det;
+    m_P2I[6] = c02 / det; m_P2I[7] = (i2p[1] * i2p[6] - i2p[0] * i2p[7]) / det; m_P2I[8] = (i2p[0] * i2p[4] - i2p[1] * i2p[3]) / det;
+  }
+
+  // linearly interpolated gradient at a physical point, as a CovariantVector<float,3> would hold it
+  void Evaluate(const double p[3], float g[3]) const
+  {
+    double cv[3], d[3];
+    long lo[3], hi[3];
+    for (int k = 0; k < 3; k++) cv[k] = p[k] - m_Origin[k];
+    for (int r = 0; r < 3; r++)
+      {
+      double ci = 0.0;
+      for (int k = 0; k < 3; k++) ci += m_P2I[r * 3 + k] * cv[k];
+      const double b = std::floor(ci);
+      d[r] = ci - b;
+      // the neighbour indices are clamped into the image (a NaN coordinate lands on index 0)
+      long bi = (b >= -1.0) ? ((b <= static_cast<double>(m_N[r])) ? static_cast<long>(b) : m_N[r]) : -1;
+      if (!(b == b)) bi = 0;
+      lo[r] = bi < 0 ? 0 : (bi > m_N[r] - 1 ? m_N[r] - 1 : bi);
+      hi[r] = bi + 1 < 0 ? 0 : (bi + 1 > m_N[r] - 1 ? m_N[r] - 1 : bi + 1);
+      }
+    double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+    for (unsigned int counter = 0; counter < 8; counter++)
+      {
+      double overlap = 1.0;
+      long idx[3];
+      for (int k = 0; k < 3; k++)
+        {
+        if (counter & (1u << k)) { idx[k] = hi[k]; overlap *= d[k]; }
+        else { idx[k] = lo[k]; overlap *= 1.0 - d[k]; }
+        }
+      if (overlap != 0.0 && total != 1.0)        // "if (overlap)" and "break once the weights add up to 1" of ITK's loop
+        {
+        float site[3];
+        SiteGradient(idx, site);
+        for (int k = 0; k < 3; k++) acc[k] += overlap * static_cast<double>(site[k]);
+        total += overlap;
+        }
+      }
+    for (int k = 0; k < 3; k++) g[k] = static_cast<float>(acc[k]);
+  }
+
+private:
+  float Pixel(long x, long y, long z) const
+  {
+    x = x < 0 ? 0 : (x > m_N[0] - 1 ? m_N[0] - 1 : x);
+    y = y < 0 ? 0 : (y > m_N[1] - 1 ? m_N[1] - 1 : y);
+    z = z < 0 ? 0 : (z > m_N[2] - 1 ? m_N[2] - 1 : z);
+    return static_cast<float>(m_Buffer[(static_cast<size_t>(z) * m_N[1] + y) * m_N[0] + x]);
+  }
+  // GradientImageFilter at one pixel: per axis the 3-tap inner product (-c, 0, +c) accumulated in float, then the
+  // direction matrix (float accumulator, double products)
+  void SiteGradient(const long idx[3], float out[3]) const
+  {
+    float local[3];
+    const float f0 = Pixel(idx[0], idx[1], idx[2]);
+    for (int a = 0; a < 3; a++)
+      {
+      const float fm = Pixel(idx[0] - (a == 0), idx[1] - (a == 1), idx[2] - (a == 2));
+      const float fp = Pixel(idx[0] + (a == 0), idx[1] + (a == 1), idx[2] + (a == 2));
+      float sum = 0.0f;
+      sum += (-m_Coef[a]) * fm;
+      sum += 0.0f * f0;
+      sum += m_Coef[a] * fp;
+      local[a] = sum;
+      }
+    for (int r = 0; r < 3; r++)
+      {
+      float sum = 0.0f;
+      for (int c = 0; c < 3; c++) sum = static_cast<float>(static_cast<double>(sum) + m_Dir[r * 3 + c] * static_cast<double>(local[c]));
+      out[r] = sum;
+      }
+  }
+  const PixelType *m_Buffer;
+  long m_N[3];
+  double m_Origin[3], m_Dir[9], m_P2I[9];
+  float m_Coef[3];
+};
+
+// txx:439-474 for the vertices [i0, i1): points are float[3] each, moved in place
+template <class TImage, class TInterpolator> struct HostWalk
+{
+  const HostGradient<TImage> *gradient;
+  const TInterpolator *interpolator;
+  float *points;
+  double iso, threshold, stepLength, relaxation;
+  unsigned int maxSteps;
+  void operator()(uint64_t i0, uint64_t i1) const
+  {
+    typename TInterpolator::PointType q;
+    for (uint64_t i = i0; i < i1; i++)
+      {
+      float *v = points + 3 * i;
+      double step = stepLength;
+      unsigned int numberOfSteps = 0;
+      bool done = false;
+      while (!done)
+        {
+        const double p[3] = {static_cast<double>(v[0]), static_cast<double>(v[1]), static_cast<double>(v[2])};
+        float normal[3];
+        gradient->Evaluate(p, normal);
+        double sq = 0.0;
+        for (int k = 0; k < 3; k++) sq += static_cast<double>(normal[k]) * static_cast<double>(normal[k]);
+        const double norm = std::sqrt(sq);
+        for (int k = 0; k < 3; k++) normal[k] = static_cast<float>(static_cast<double>(normal[k]) / norm);   // no zero guard (txx:452)
+        for (int k = 0; k < 3; k++) q[k] = p[k];
+        const double value = static_cast<double>(interpolator->Evaluate(q));
+        const double diff = value - iso;
+        done = (diff < 0 ? -diff : diff) < threshold;
+        if (!done)
+          {
+          const double sign = (value < iso) ? +1.0 : -1.0;
+          for (int k = 0; k < 3; k++)
+            v[k] = static_cast<float>(static_cast<double>(v[k]) + (static_cast<double>(normal[k]) * sign * step));
+          step *= relaxation;
+          done = numberOfSteps++ > maxSteps;
+          }
+        }
+      }
+  }
+};
+
+// txx:286-321 on flat buffers: quads (4 ids) -> two triangles along the shorter diagonal, ties to the first form
+inline void SplitQuads(const float *points, const uint64_t *quads, uint64_t nQuads, uint64_t *triangles)
+{
+  for (uint64_t c = 0; c < nQuads; c++)
+    {
+    const uint64_t *f = quads + 4 * c;
+    double d02 = 0.0, d13 = 0.0;
+    for (int k = 0; k < 3; k++)
+      {
+      const double a = static_cast<double>(points[3 * f[2] + k]) - static_cast<double>(points[3 * f[0] + k]);
+      const double b = static_cast<double>(points[3 * f[3] + k]) - static_cast<double>(points[3 * f[1] + k]);
+      d02 += a * a;
+      d13 += b * b;
+      }
+    uint64_t *t = triangles + 6 * c;
+    if (d02 >= d13) { t[0] = f[0]; t[1] = f[1]; t[2] = f[3]; t[3] = f[1]; t[4] = f[2]; t[5] = f[3]; }
+    else { t[0] = f[0]; t[1] = f[1]; t[2] = f[2]; t[3] = f[0]; t[4] = f[2]; t[5] = f[3]; }
+    }
+}
+
 // the one interpolator the kernels implement (I5: linear, double coordinates)
 template <class TInterpolator, class TImage> struct IsGpuInterpolator { enum { Value = 0 }; };
 template <class TImage> struct IsGpuInterpolator<LinearInterpolateImageFunction<TImage, double>, TImage> { enum { Value = 1 }; };
@@ -140,8 +320,9 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   const unsigned int Dim = InputImageType::ImageDimension;
   if (Dim != 3) itkExceptionMacro(<< "the cuberille path is three-dimensional");
   if (cuberille_detail::PixelCode<InputPixelType>::Value < 0) itkExceptionMacro(<< "unsupported pixel type");
-  if (m_ProjectVerticesToIsoSurface && !cuberille_detail::IsGpuInterpolator<TInterpolator, TInputImage>::Value)
-    itkExceptionMacro(<< "only itk::LinearInterpolateImageFunction<TInputImage,double> is implemented by the MI355X path");
+  // any other TInterpolator than the linear one the kernels implement: topology and lattice points on the GPU,
+  // the walk on the host through the user's interpolator (see HostWalk above)
+  const bool hostWalk = m_ProjectVerticesToIsoSurface && !cuberille_detail::IsGpuInterpolator<TInterpolator, TInputImage>::Value;
 
   // parameter resolution exactly where the reference does it: largest spacing, then the default
   // step length, which sticks to the filter object once resolved
@@ -167,8 +348,8 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
 
   cuberille_params prm;
   prm.iso_value = static_cast<double>(m_IsoSurfaceValue);
-  prm.generate_triangles = m_GenerateTriangleFaces ? 1 : 0;
-  prm.project_vertices = m_ProjectVerticesToIsoSurface ? 1 : 0;
+  prm.generate_triangles = (m_GenerateTriangleFaces && !hostWalk) ? 1 : 0;   // the split needs the projected points
+  prm.project_vertices = (m_ProjectVerticesToIsoSurface && !hostWalk) ? 1 : 0;
   prm.distance_threshold = m_ProjectVertexSurfaceDistanceThreshold;
   prm.step_length = m_ProjectVertexStepLength;
   prm.relaxation = m_ProjectVertexStepLengthRelaxationFactor;
@@ -196,6 +377,26 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
     itkExceptionMacro(<< "cuberille_mesh_download: " << cuberille_last_error(m_Context));
     }
   m_LastDownloadSeconds = cuberille_detail::WallSeconds() - downloadStart;
+
+  if (hostWalk)
+    {
+    cuberille_detail::HostGradient<InputImageType> gradient(image.GetPointer());
+    cuberille_detail::HostWalk<InputImageType, TInterpolator> walk =
+      {&gradient, m_Interpolator.GetPointer(), points, static_cast<double>(m_IsoSurfaceValue),
+       m_ProjectVertexSurfaceDistanceThreshold, m_ProjectVertexStepLength, m_ProjectVertexStepLengthRelaxationFactor,
+       m_ProjectVertexMaximumNumberOfSteps};
+    cuberille_detail::ParallelRanges(res.n_points, walk);
+    if (m_GenerateTriangleFaces)
+      {
+      uint64_t *tri = static_cast<uint64_t *>(std::malloc(sizeof(uint64_t) * (res.n_cells * 6 + 1)));
+      if (!tri) { std::free(points); std::free(cells); itkExceptionMacro(<< "out of host memory for the mesh buffers"); }
+      cuberille_detail::SplitQuads(points, cells, res.n_cells, tri);
+      std::free(cells);
+      cells = tri;
+      res.n_cells *= 2;
+      res.verts_per_cell = 3;
+      }
+    }
 
   const double fillStart = cuberille_detail::WallSeconds();
   // points by value, straight into the container's elements

@@ -11,6 +11,81 @@
 #include "itkMesh.h"
 #include "itkCuberilleImageToMeshFilter.h"
 
+// A user's interpolator type (TInterpolator): a distinct class the filter has never seen.
+// It inherits the linear Evaluate, so the host walk that calls it must land exactly where the GPU walk lands.
+template <class TImage> class UserInterpolator : public itk::LinearInterpolateImageFunction<TImage, double>
+{
+public:
+  typedef UserInterpolator Self;
+  typedef itk::SmartPointer<Self> Pointer;
+  itkNewMacro(Self);
+  mutable unsigned long calls;
+  typename itk::LinearInterpolateImageFunction<TImage, double>::OutputType
+  Evaluate(const typename itk::LinearInterpolateImageFunction<TImage, double>::PointType &p) const
+  {
+    return itk::LinearInterpolateImageFunction<TImage, double>::Evaluate(p);
+  }
+protected:
+  UserInterpolator() : calls(0) {}
+};
+
+// the filter with the user's interpolator type against the filter with the default one, same image, unit spacing
+static bool user_interpolator_matches(bool triangles)
+{
+  typedef itk::Image<float, 3> ImageType;
+  typedef itk::Mesh<float, 3> MeshType;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType> GpuFilter;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType, UserInterpolator<ImageType> > UserFilter;
+  const int n = 48;
+  ImageType::Pointer image = ImageType::New();
+  ImageType::RegionType region;
+  ImageType::IndexType start;
+  ImageType::SizeType size;
+  start.Fill(0);
+  size.Fill(n);
+  region.SetIndex(start);
+  region.SetSize(size);
+  image->SetRegions(region);
+  image->Allocate();
+  for (int z = 0; z < n; z++)
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++)
+        {
+        ImageType::IndexType idx;
+        idx[0] = x; idx[1] = y; idx[2] = z;
+        const double r = std::sqrt((x - 23.3) * (x - 23.3) + (y - 23.6) * (y - 23.6) + (z - 23.1) * (z - 23.1));
+        image->SetPixel(idx, static_cast<float>(17.0 - r + 0.3 * std::sin(0.9 * x) * std::cos(0.7 * y)));
+        }
+  GpuFilter::Pointer a = GpuFilter::New();
+  UserFilter::Pointer b = UserFilter::New();
+  a->SetInput(image); b->SetInput(image);
+  a->SetIsoSurfaceValue(0.0f); b->SetIsoSurfaceValue(0.0f);
+  a->SetGenerateTriangleFaces(triangles); b->SetGenerateTriangleFaces(triangles);
+  a->SetProjectVertexSurfaceDistanceThreshold(0.01); b->SetProjectVertexSurfaceDistanceThreshold(0.01);
+  a->Update();
+  b->Update();
+  MeshType::Pointer ma = a->GetOutput(), mb = b->GetOutput();
+  bool same = ma->GetNumberOfPoints() == mb->GetNumberOfPoints() && ma->GetNumberOfCells() == mb->GetNumberOfCells();
+  unsigned long moved = 0;
+  for (unsigned long i = 0; same && i < ma->GetNumberOfPoints(); i++)
+    {
+    MeshType::PointType pa, pb;
+    ma->GetPoint(i, &pa); mb->GetPoint(i, &pb);
+    for (int k = 0; k < 3; k++) same = same && (pa[k] == pb[k]);
+    if (pa[0] != std::floor(pa[0]) + 0.5f) moved++;
+    }
+  for (unsigned long c = 0; same && c < ma->GetNumberOfCells(); c++)
+    {
+    MeshType::CellAutoPointer ca, cb;
+    ma->GetCell(c, ca); mb->GetCell(c, cb);
+    same = ca->GetNumberOfPoints() == cb->GetNumberOfPoints();
+    for (unsigned int k = 0; same && k < ca->GetNumberOfPoints(); k++) same = ca->PointIdsBegin()[k] == cb->PointIdsBegin()[k];
+    }
+  std::cout << "user-interpolator" << (triangles ? "-triangles " : " ") << ma->GetNumberOfPoints() << " " << ma->GetNumberOfCells() << " "
+            << (same && moved > 100 ? 2 : -1) << std::endl;
+  return same && moved > 100;
+}
+
 template <class TPixel>
 bool run(const char *name, bool triangles, unsigned long &points, unsigned long &cells)
 {
@@ -87,6 +162,9 @@ int main()
     unsigned long pt, ct;
     ok &= run<float>("float-triangles", true, pt, ct);
     ok &= (pt == p[4]) && (ct == 2 * c[4]);
+    // TInterpolator other than the linear one the kernels implement: GPU topology, host walk through the user's class
+    ok &= user_interpolator_matches(false);
+    ok &= user_interpolator_matches(true);
     return ok ? 0 : 1;
     }
   catch (itk::ExceptionObject &e)
