@@ -179,12 +179,11 @@ def main():
     strong = world == 1 or args.scaling == "strong"
     gnz = n if strong else n * world
     ex = pkg.Extractor(local_rank)
-    # weak mode stacks copies of the block along z; for Marschner-Lobb every copy ends in a run of empty slices, across
-    # which the reference re-uses vertex ids (quirk Q1) -- at every slab boundary here.  The library refuses
-    # to shard that silently, so the weak-scaling volume is extracted with the emulation off (stated in config).
-    q1 = strong
+    # (weak mode stacks copies of the block along z; for Marschner-Lobb every copy ends in a run of empty slices, across
+    #  which the reference re-uses vertex ids -- quirk Q1, DESIGN.md -- at every slab boundary: the driver hands the
+    #  source slices between the ranks, two more small exchanges per step)
     prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
-                          max_steps=50, q1=q1)
+                          max_steps=50)
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm)
     period = None if strong else n
     if args.workload == "sphere" and not strong:
@@ -276,7 +275,7 @@ def main():
             "config": {"workload": "%s %dx%dx%d %s iso=%g, triangles+projection (thr %g, step 0.25, relax 0.95, max 50)"
                                    % (args.workload, n, n, gnz, np.dtype(dtype).name, iso, thr),
                        "per_gpu": "%dx%dx%d slab + %d-slice halo" % (n, n, sh.z1 - sh.z0, sh.halo if world > 1 else 0),
-                       "parallelism": "zslab%d" % world + ("" if q1 else " (empty-slice aliasing emulation off)"),
+                       "parallelism": "zslab%d" % world,
                        "points": n_points, "cells": n_cells,
                        "projection_iterations_rank0": int(res.proj_iterations)},
             # the HBM-bound pass the north star's target is defined on: threshold sweep +

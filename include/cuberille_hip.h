@@ -155,6 +155,22 @@ int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_par
 /* After cuberille_count on a slab: see cuberille_slab_status. */
 int cuberille_slab_info(cuberille_ctx *ctx, cuberille_slab_status *out);
 
+/* Quirk Q1 across a slab boundary (the reference re-uses the vertices of the last occupied slice below a run of
+ * empty slices, txx:139-141 before 156-161).  When a slab's first occupied slice has only empty
+ * slices below it in the buffer (cuberille_slab_status.alias_source_below_buffer) and a rank below holds an occupied
+ * slice zp, four calls reproduce the reference:
+ *   below: cuberille_slice_bits_device(zp)        -> the inside bits of slice zp (device pointer, n_words words)
+ *   above: cuberille_recount(those bits)          -> the counts with the re-used vertices no longer created
+ *   below, after its cuberille_emit:
+ *          cuberille_alias_plane_device(zp, ids, points) -> global id and final position of the vertex under every
+ *                                                    (x, y) corner key of the plane above slice zp, (nx+1)(ny+1) entries
+ *   above: cuberille_set_alias_plane(ids, points); cuberille_emit(...) -> cells that reference those vertices
+ * All pointers are device pointers of the calling context's device (the driver moves them between ranks). */
+int cuberille_slice_bits_device(cuberille_ctx *ctx, int64_t z_global, const uint64_t **dev_words, size_t *n_words);
+int cuberille_recount(cuberille_ctx *ctx, const void *dev_source_bits, uint64_t *n_points, uint64_t *n_cells);
+int cuberille_alias_plane_device(cuberille_ctx *ctx, int64_t z_global, uint64_t *dev_ids, float *dev_points);
+int cuberille_set_alias_plane(cuberille_ctx *ctx, const uint64_t *dev_ids, const float *dev_points);
+
 /* Result buffers of the last extract/emit (valid until the next call on this context):
  * points = float[3*n_points], cells = uint64[verts_per_cell*n_cells] holding GLOBAL point ids. */
 int cuberille_mesh_device(const cuberille_ctx *ctx, const float **d_points, const uint64_t **d_cells);

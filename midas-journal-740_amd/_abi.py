@@ -22,6 +22,7 @@ EXPORTS = [
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
+    "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
 ]
 ABI_VERSION = 4
 
@@ -117,6 +118,10 @@ def lib():
     L.cuberille_slab_info.argtypes = [vp, C.POINTER(SlabStatus)]
     L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cuberille_debug_h2d_seconds.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double)]
+    L.cuberille_slice_bits_device.argtypes = [vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.cuberille_recount.argtypes = [vp, vp, u64p, u64p]
+    L.cuberille_alias_plane_device.argtypes = [vp, C.c_int64, vp, vp]
+    L.cuberille_set_alias_plane.argtypes = [vp, vp, vp]
     _lib = L
     return L
 

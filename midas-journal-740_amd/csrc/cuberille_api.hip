@@ -58,6 +58,11 @@ struct cuberille_ctx {
   size_t stageBytes = 0;
   hipEvent_t stageFree[2] = {}, chunkIn[2] = {};
   bool aliasBelowBuffer = false;         // soft condition of the last slab count (cuberille_slab_info)
+  bool aliasMustResolve = false;         // ... and it is certain: the source slice lies in this slab's own halo
+  bool slabMode = false;                 // the last count was given a slab
+  u64 pointOffset = 0;                   // of the last emit
+  const u64 *extIds = nullptr;           // cuberille_set_alias_plane: planes for the next emit (device pointers)
+  const float *extPts = nullptr;
   // state of the last count
   bool counted = false, haveMesh = false, slabMesh = false;
   Grid g{};
@@ -252,6 +257,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->counted = false;
   c->haveMesh = false;
   c->aliasBelowBuffer = false;
+  c->aliasMustResolve = false;
   HIP_TRY(c, hipSetDevice(c->device));
 
   // ---- layout -----------------------------------------------------------------------------
@@ -301,7 +307,11 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   if (nseg > 0x7fffffffULL) return fail(c, CUBERILLE_ERR_LIMIT, "volume too large for one device scan");
 
   // ---- workspace ----------------------------------------------------------------------------------
-  HIP_TRY(c, c->bits.reserve(nwordsAll * sizeof(u64)));
+  // (+ one slice past the buffer: a slab may be handed the source slice of quirk Q1 from the rank below)
+  HIP_TRY(c, c->bits.reserve((nwordsAll + (size_t)g.ny * g.W) * sizeof(u64)));
+  c->slabMode = !whole;
+  c->extIds = nullptr;
+  c->extPts = nullptr;
   HIP_TRY(c, c->occ.reserve((size_t)g.nzb * sizeof(u32)));
   HIP_TRY(c, c->prefix.reserve(nwords * sizeof(u32)));
   HIP_TRY(c, c->segPre.reserve(nseg * sizeof(u64)));
@@ -344,10 +354,10 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->tot = *c->hostTotals;
-  if (c->tot.err & ERRF_ALIAS_UNKNOWN)
-    return fail(c, CUBERILLE_ERR_HALO,
-                "an empty slice makes the reference re-use vertices created below this slab's counted range (DESIGN.md Q1)");
-  c->aliasBelowBuffer = (c->tot.err & ERRF_ALIAS_BELOW_BUFFER) != 0;
+  // quirk Q1 reaching below this slab: certain when the source slice is in the halo (the emit then insists on
+  // cuberille_recount), possible when the search ran off the buffer's bottom (the ranks below know)
+  c->aliasMustResolve = (c->tot.err & ERRF_ALIAS_UNKNOWN) != 0;
+  c->aliasBelowBuffer = (c->tot.err & (ERRF_ALIAS_BELOW_BUFFER | ERRF_ALIAS_UNKNOWN)) != 0;
   c->counted = true;
   std::memset(&c->res, 0, sizeof(c->res));
   c->res.n_points = c->tot.totV - c->tot.V0;
@@ -396,16 +406,70 @@ int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const voi
   return count_finish(c, n_points, n_cells);
 }
 
+int cuberille_recount(cuberille_ctx *c, const void *dev_source_bits, uint64_t *n_points, uint64_t *n_cells) {
+  if (!c || !dev_source_bits) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted || !c->slabMode)
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_recount follows a successful cuberille_count on a slab");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t sliceWords = (size_t)c->g.ny * c->g.W;
+  // the source slice goes one past the buffer's last slice; the count then finds it where alias_of points
+  HIP_TRY(c, hipMemcpyAsync((u64 *)c->bits.p + sliceWords * (size_t)c->g.nzb, dev_source_bits, sliceWords * sizeof(u64),
+                            hipMemcpyDeviceToDevice, s));
+  c->g.extAlias = 1;
+  c->counted = false;
+  HIP_TRY(c, hipMemsetAsync(c->w.totals, 0, sizeof(Totals), s));
+  return count_finish(c, n_points, n_cells);
+}
+
+int cuberille_slice_bits_device(cuberille_ctx *c, int64_t z_global, const uint64_t **dev_words, size_t *n_words) {
+  if (!c || !dev_words || !n_words) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no classified volume on this context");
+  const long long z = z_global - c->g.zglob0;
+  if (z < 0 || z >= c->g.nzb) return fail(c, CUBERILLE_ERR_ARGUMENT, "slice outside the buffer");
+  *n_words = (size_t)c->g.ny * c->g.W;
+  *dev_words = (const uint64_t *)c->bits.p + *n_words * (size_t)z;
+  return CUBERILLE_OK;
+}
+
+int cuberille_alias_plane_device(cuberille_ctx *c, int64_t z_global, uint64_t *dev_ids, float *dev_points) {
+  if (!c || !dev_ids || !dev_points) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: the plane is built from the last emit");
+  const long long z = z_global - c->g.zglob0;
+  if (z < c->g.oz0 || z >= c->g.oz1) return fail(c, CUBERILLE_ERR_ARGUMENT, "slice outside the owned range");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_alias_plane(c->w, c->g, (int)z, c->pointOffset, (u64 *)dev_ids, dev_points, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CUBERILLE_OK;
+}
+
+int cuberille_set_alias_plane(cuberille_ctx *c, const uint64_t *dev_ids, const float *dev_points) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted || !c->g.extAlias)
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_set_alias_plane follows cuberille_recount and precedes cuberille_emit");
+  c->extIds = (const u64 *)dev_ids;
+  c->extPts = dev_points;
+  return CUBERILLE_OK;
+}
+
 int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit called before a successful cuberille_count");
+  if (c->g.extAlias && (!c->extIds || !c->extPts))
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
+  if (c->aliasMustResolve)
+    return fail(c, CUBERILLE_ERR_HALO,
+                "an empty slice makes the reference re-use vertices created below this slab's counted range: hand the "
+                "source slice over with cuberille_recount (DESIGN.md Q1)");
   (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
   c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
+  c->pointOffset = point_id_offset;
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 nV = c->tot.totV;                 // ghost + owned
   const u64 nGhost = c->tot.V0;
   const u64 nQ = c->tot.totQ - c->tot.Q0;
-  HIP_TRY(c, c->points.reserve((size_t)(nV ? nV : 1) * 3 * sizeof(float)));
+  const size_t planeCorners = c->g.extAlias ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
+  HIP_TRY(c, c->points.reserve((size_t)(nV + planeCorners ? nV + planeCorners : 1) * 3 * sizeof(float)));
   HIP_TRY(c, c->cells.reserve((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
   Workspace &w = c->w;
   w.points = (float *)c->points.p;
@@ -432,7 +496,9 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, s));
   HIP_TRY(c, hipEventRecord(c->ev[6], s));
-  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, s));
+  if (planeCorners)
+    HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, c->extIds, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));

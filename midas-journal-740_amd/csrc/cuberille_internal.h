@@ -36,6 +36,9 @@ struct Grid {
   int oz0, oz1;        // local slices [oz0, oz1) this rank emits
   long long zglob0;    // global z of local slice 0
   long long gnz;       // global Nz
+  int extAlias;        // 1: slice nzb of the bit volume (one past the buffer) holds the inside bits of the occupied slice
+                       //    the rank below reported, the source of quirk Q1's vertex re-use for this slab's first
+                       //    occupied slice (cuberille_recount)
 };
 
 struct Totals {        // device-resident, zeroed before every count, mirrored to pinned host memory
@@ -100,7 +103,10 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
 hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
                               const Tuning &t, hipStream_t s);
-hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ, hipStream_t s);
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
+                             const u64 *extIds, hipStream_t s);
+hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
+                              hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, hipStream_t s);
 

@@ -307,14 +307,18 @@ __global__ __launch_bounds__(256) void k_occupancy(const u64 *__restrict__ bits,
 // the top-plane corners of zp.  Returns zp or -1.  The usual answer costs one cached load.
 // unknown (an ERRF_* bit, raised by the count kernel): the source lies in the buffer but below the counted range
 // [cz0, ..) -- its ids belong to the rank below -- or the search fell off the bottom of a slab buffer that does not
-// start at the volume's first slice (the multi-GPU driver knows whether anything is occupied down there).
+// start at the volume's first slice (the multi-GPU driver knows whether anything is occupied down there).  Either
+// way the rank below can hand the source slice over (Grid::extAlias, cuberille_recount).
 __device__ __forceinline__ int alias_of(const u32 *__restrict__ occ, const Grid &g, int q1, int z, u32 &unknown) {
   unknown = 0;
   if (!q1 || z <= 0 || occ[z - 1]) return -1;
   int p = z - 2;
   while (p >= 0 && !occ[p]) p--;
-  if (p >= 0 && p < g.cz0 && z >= g.cz0) { unknown = ERRF_ALIAS_UNKNOWN; return -1; }
-  if (p < 0 && g.zglob0 > 0) unknown = ERRF_ALIAS_BELOW_BUFFER;
+  if ((p >= 0 && p < g.cz0 && z >= g.cz0) || (p < 0 && g.zglob0 > 0)) {
+    if (g.extAlias) return g.nzb;      // the source slice came from the rank below: it sits one past the buffer
+    unknown = p >= 0 ? ERRF_ALIAS_UNKNOWN : ERRF_ALIAS_BELOW_BUFFER;
+    return -1;
+  }
   return p;
 }
 
@@ -741,6 +745,8 @@ struct EmitArgs {
   u64 pointOffset;     // global id of this rank's first point
   u32 *cmap;           // dense lattice-corner -> vertex index map, or null (see corner_map_index)
   const u32 *headV, *headQ;   // word producing output 64*i (k_heads), or null
+  const u64 *extIds;   // Grid::extAlias: global ids of the top-plane corners of the source slice, dense (nx+1) x (ny+1);
+                       // their positions stand behind this rank's own points, from index totV on
 };
 
 // absolute exclusive prefix (SHIFT 0: vertices, 16: quads) at the start of the segment that holds word gi
@@ -1036,7 +1042,8 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
                                               u64 (&o)[TRI ? 6 : 4]) {
   u32 unk;
   const int zp = alias_of(a.occ, g, a.q1, z, unk);
-  u64 lid[4];                                    // vertex index in the counted range
+  u64 lid[4], ext[4];                            // vertex index in the counted range
+  unsigned isExt = 0;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int i = kFaceCorner[f][c];
@@ -1053,14 +1060,23 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
       }
       if (hit) cz = zp + 1;
     }
+    ext[c] = 0;
+    if (cz == g.nzb + 1) {
+      // a vertex of the rank below (quirk Q1 across the slab boundary): its global id comes from the plane that rank
+      // sent, its position stands behind this rank's own points
+      const u64 j = (u64)cy * (u64)(g.nx + 1) + (u64)cx;
+      ext[c] = a.extIds[j];
+      lid[c] = a.tot->totV + j;
+      isExt |= 1u << c;
+    }
     // MAP: ids from the dense corner map; otherwise recomputed (kept out of the MAP instantiation: its
     // 27-row classification would cost the common kernel a quarter of its wave slots)
-    if (MAP) lid[c] = (u64)a.cmap[corner_map_index(g, cx, cy, cz)];
+    else if (MAP) lid[c] = (u64)a.cmap[corner_map_index(g, cx, cy, cz)];
     else lid[c] = corner_id_generic(a, g, cx, cy, cz);
   }
   u64 id[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) id[c] = lid[c] - V0 + a.pointOffset;
+  for (int c = 0; c < 4; c++) id[c] = ((isExt >> c) & 1u) ? ext[c] : lid[c] - V0 + a.pointOffset;
   if constexpr (!TRI) {
     o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
   } else {
@@ -1696,6 +1712,7 @@ static EmitArgs emit_args(const Workspace &w, const Grid &g, int q1, u64 pointOf
   a.pointOffset = pointOffset;
   a.cmap = w.cmap;
   a.headV = w.headV; a.headQ = w.headQ;
+  a.extIds = nullptr;
   return a;
 }
 
@@ -1721,10 +1738,45 @@ hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo,
   return hipGetLastError();
 }
 
-hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ, hipStream_t s) {
+// Quirk Q1 across a slab boundary, the serving side: for every lattice corner (cx, cy) on the plane above local slice
+// z (this rank's highest occupied slice; everything above it in its range is empty) the global id and the final
+// position of the vertex the reference would find under that (x, y) key -- it exists when an inside voxel of slice z
+// touches the corner -- or ~0 where there is none.  The rank above re-uses these for its first occupied slice.
+__global__ __launch_bounds__(256) void k_alias_plane(EmitArgs a, Grid g, int z, u64 *__restrict__ idsOut, float *__restrict__ ptsOut) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 n = (u64)(g.nx + 1) * (u64)(g.ny + 1);
+  if (j >= n) return;
+  const int cx = (int)(j % (u64)(g.nx + 1)), cy = (int)(j / (u64)(g.nx + 1));
+  bool hit = false;
+  for (int ee = 0; ee < 4; ee++) {
+    const int vx = cx - (ee & 1), vy = cy - (ee >> 1);
+    if (vx >= 0 && vx < g.nx && vy >= 0 && vy < g.ny && getbit(a.bits, g, vx, vy, z)) hit = true;
+  }
+  u64 id = ~0ull;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (hit) {
+    const u64 lid = a.cmap ? (u64)a.cmap[corner_map_index(g, cx, cy, z + 1)] : corner_id_generic(a, g, cx, cy, z + 1);
+    id = lid - a.tot->V0 + a.pointOffset;
+    p[0] = a.points[3 * lid]; p[1] = a.points[3 * lid + 1]; p[2] = a.points[3 * lid + 2];
+  }
+  idsOut[j] = id;
+  ptsOut[3 * j] = p[0]; ptsOut[3 * j + 1] = p[1]; ptsOut[3 * j + 2] = p[2];
+}
+
+hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
+                              hipStream_t s) {
+  const EmitArgs a = emit_args(w, g, 1, pointOffset);
+  const u64 n = (u64)(g.nx + 1) * (u64)(g.ny + 1);
+  hipLaunchKernelGGL(k_alias_plane, dim3(grid_for(n, 256, 0)), dim3(256), 0, s, a, g, zLocal, idsOut, ptsOut);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
+                             const u64 *extIds, hipStream_t s) {
   if (!nQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const EmitArgs a = emit_args(w, g, q1, pointOffset);
+  EmitArgs a = emit_args(w, g, q1, pointOffset);
+  a.extIds = extIds;
   const dim3 grid(grid_for(nQ, 256, 0)), block(256);
   if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nwords, nQ);
   else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nwords, nQ);

@@ -190,6 +190,25 @@ class Extractor:
         _abi.check(self._ctx, self._lib.cuberille_slab_info(self._ctx, C.byref(st)))
         return bool(st.alias_source_below_buffer), int(st.lowest_occupied_z), int(st.highest_occupied_z)
 
+    # -- quirk Q1 across a slab boundary (include/cuberille_hip.h) ------------------------------------------------
+    def slice_bits_device(self, z_global):
+        """(device pointer, n_words) of the inside bits of one buffer slice."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _abi.check(self._ctx, self._lib.cuberille_slice_bits_device(self._ctx, int(z_global), C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
+    def recount(self, dev_source_bits):
+        npnt, ncell = C.c_uint64(), C.c_uint64()
+        _abi.check(self._ctx, self._lib.cuberille_recount(self._ctx, C.c_void_p(dev_source_bits), C.byref(npnt), C.byref(ncell)))
+        return int(npnt.value), int(ncell.value)
+
+    def alias_plane_device(self, z_global, dev_ids, dev_points):
+        _abi.check(self._ctx, self._lib.cuberille_alias_plane_device(self._ctx, int(z_global), C.c_void_p(dev_ids),
+                                                                     C.c_void_p(dev_points)))
+
+    def set_alias_plane(self, dev_ids, dev_points):
+        _abi.check(self._ctx, self._lib.cuberille_set_alias_plane(self._ctx, C.c_void_p(dev_ids), C.c_void_p(dev_points)))
+
     def debug_option(self, name, value):
         """Development switch of this context (cuberille_debug_set_option); "defaults" resets them all."""
         _abi.check(self._ctx, self._lib.cuberille_debug_set_option(self._ctx, name.encode(), int(value)))

@@ -118,6 +118,36 @@ def id_offsets(counts, rank):
     return int(c[:rank, 0].sum()), int(c[:rank, 1].sum())
 
 
+def alias_plan(rows):
+    """From the gathered per-rank rows [n_points, n_cells, alias_source_below_buffer, highest_occupied_z, failed]:
+    the (consumer rank, source rank, source slice) triples of quirk Q1 crossing slab boundaries.  A rank whose first
+    occupied slice has nothing but empty slices below it in its buffer re-uses the vertices of the highest occupied
+    slice any rank below it owns (ranks in between hold no occupied slice at all)."""
+    plan = []
+    rows = np.asarray(rows)
+    for r in range(1, rows.shape[0]):
+        if rows[r, 2] and (rows[:r, 3] >= 0).any():
+            src = int(np.argmax(rows[:r, 3]))
+            plan.append((r, src, int(rows[src, 3])))
+    return plan
+
+
+def _p2p_send(t, dst, group):
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        t = t.cpu()
+    dist.send(t.contiguous(), dst, group=group)
+
+
+def _p2p_recv(shape, dtype, device, src, group):
+    import torch
+    import torch.distributed as dist
+    staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+    t = torch.empty(shape, dtype=dtype, device="cpu" if staged else device)
+    dist.recv(t, src, group=group)
+    return t.to(device) if staged else t
+
+
 def aliasing_crosses_slabs(occupied, bounds):
     """Quirk Q1 check on the gathered per-slice occupancy (bool[global_nz]).  The reference re-uses
     vertices across an EMPTY slice (txx:139-141 precede 156-161); a rank can only reproduce that
@@ -140,12 +170,15 @@ class ShardedExtractor:
     """Multi-GPU driver: one instance per rank, wraps one Extractor."""
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
-                 origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None):
+                 origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
+                 cross_slab_aliasing=True):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
-        check_aliasing: raise when quirk Q1 (vertex re-use across an empty slice) would cross a slab boundary
-        instead of returning a mesh that differs from the single-GPU one; costs nothing extra (the flags ride
-        in the count all-gather)."""
+        check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
+        nothing extra, the flags ride in the count all-gather -- and, cross_slab_aliasing, reproduce it: the rank below
+        sends the source slice's inside bits (the rank above counts again), later the ids and positions of that slice's
+        top-plane vertices; with cross_slab_aliasing off the case raises instead.  check_aliasing off returns whatever
+        the ranks computed on their own (a mesh that differs from the single-GPU one in that case)."""
         from . import _abi
         from .cuberille import make_desc, required_halo
         self.ex = extractor
@@ -166,6 +199,7 @@ class ShardedExtractor:
         self._halo_event = None
         self._vox_event = None
         self.check_aliasing = check_aliasing
+        self.cross_slab_aliasing = cross_slab_aliasing
         self.counts = None
 
     def extract(self, buf, params):
@@ -225,13 +259,52 @@ class ShardedExtractor:
         if rows[:, 4].any():
             bad = [int(r) for r in np.nonzero(rows[:, 4])[0]]
             raise RuntimeError("cuberille_count failed on rank(s) %s%s" % (bad, ": %s" % failed if failed is not None else ""))
-        if self.check_aliasing:
-            for r in range(1, self.world):
-                # rank r assumed that nothing is occupied below its buffer; a rank below says otherwise
-                if rows[r, 2] and (rows[:r, 3] >= 0).any():
-                    raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % r)
+        # quirk Q1 across slab boundaries: rank r assumed that nothing is occupied below its buffer; a rank below says
+        # otherwise.  Every rank derives the same plan from the gathered rows.
+        plan = alias_plan(rows) if self.check_aliasing else []
+        if plan and not self.cross_slab_aliasing:
+            raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % plan[0][0])
+        dev = buf.device
+        n_words = self.ny * ((self.nx + 63) // 64)
+        n_corners = (self.nx + 1) * (self.ny + 1)
+        for r, src, zp in plan:
+            # the consumer counts again with the source slice's inside bits at hand: the re-used vertices are no
+            # longer created
+            if self.rank == src:
+                ptr, n = self.ex.slice_bits_device(zp)
+                _p2p_send(torch.as_tensor(_DeviceArray(ptr, (n,), "<i8"), device=dev), r, self.group)
+            if self.rank == r:
+                bits = _p2p_recv((n_words,), torch.int64, dev, src, self.group)
+                if dev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+                n_p, n_c = self.ex.recount(bits.data_ptr())
+                del bits
+        if plan:
+            self.counts = gather_counts(n_p, n_c, dev, self.group)
         poff, coff = id_offsets(self.counts, self.rank)
-        return self.ex.emit(poff, coff)
+        mine = [e for e in plan if e[0] == self.rank]
+        serve = [e for e in plan if e[1] == self.rank]
+        planes = None
+        if mine:
+            # ids and final positions of the vertices under the (x, y) corner keys of the source slice's top plane
+            _, src, _ = mine[0]
+            ids = _p2p_recv((n_corners,), torch.int64, dev, src, self.group)
+            pts = _p2p_recv((n_corners, 3), torch.float32, dev, src, self.group)
+            if dev.type == "cuda":
+                torch.cuda.current_stream().synchronize()
+            self.ex.set_alias_plane(ids.data_ptr(), pts.data_ptr())
+            planes = (ids, pts)
+        res = self.ex.emit(poff, coff)
+        del planes
+        for r, _, zp in serve:
+            ids = torch.empty((n_corners,), dtype=torch.int64, device=dev)
+            pts = torch.empty((n_corners, 3), dtype=torch.float32, device=dev)
+            if dev.type == "cuda":
+                torch.cuda.current_stream().synchronize()
+            self.ex.alias_plane_device(zp, ids.data_ptr(), pts.data_ptr())
+            _p2p_send(ids, r, self.group)
+            _p2p_send(pts, r, self.group)
+        return res
 
     def gather_mesh(self, dst=0, on_device=None):
         """Concatenate the rank parts in rank order on rank `dst` (collective 3): the

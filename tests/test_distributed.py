@@ -80,6 +80,21 @@ def test_halo_exchange_and_offsets_gloo(tmp_path, world, nz):
     assert got_c.dtype == np.uint64 and np.array_equal(got_c, want_c)
 
 
+def test_alias_plan():
+    """Who serves whom when quirk Q1 crosses slab boundaries: rows = [points, cells, alias source below buffer,
+    highest occupied slice, failed] per rank."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from midas_journal_740_amd import distributed as D
+    assert D.alias_plan([[5, 5, 0, 30, 0], [5, 5, 0, 60, 0]]) == []
+    assert D.alias_plan([[5, 5, 0, 30, 0], [5, 5, 1, 60, 0]]) == [(1, 0, 30)]
+    assert D.alias_plan([[0, 0, 0, -1, 0], [5, 5, 1, 60, 0]]) == []                    # nothing occupied below
+    # an empty rank in between: rank 2 re-uses rank 0's vertices; rank 3 those of rank 2
+    assert D.alias_plan([[5, 5, 0, 10, 0], [0, 0, 0, -1, 0], [5, 5, 1, 40, 0], [5, 5, 1, 70, 0]]) == [(2, 0, 10), (3, 2, 40)]
+
+
 def test_slab_plan():
     import sys
     sys.path.insert(0, ROOT)
@@ -147,7 +162,8 @@ def _fake_worker(rank, world, port, scenario, out_dir):
             return types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
         fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, result=None)
         prm = pkg.make_params(0.5)
-        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm)
+        # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused)
+        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm, cross_slab_aliasing=False)
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx))
         err = ""
