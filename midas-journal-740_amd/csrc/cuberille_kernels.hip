@@ -1328,7 +1328,12 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
                                             float G[8][3], typename SiteValue<T>::type Vd[8]) {
   const bool unit = c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2];
   const int zl = c.lo[2] - s.zglob0;              // buffer slice of the cell's lower z
-  if (unit && c.lo[0] >= 1 && c.lo[0] + 2 < s.nx && c.lo[1] >= 1 && c.lo[1] + 2 < s.ny && zl >= 1 && zl + 2 < s.nzb) {
+  const bool interior = unit && c.lo[0] >= 1 && c.lo[0] + 2 < s.nx && c.lo[1] >= 1 && c.lo[1] + 2 < s.ny && zl >= 1 && zl + 2 < s.nzb;
+  // one address form per gather pass: the immediate-offset form only when EVERY lane gathering now sits in the
+  // interior; a wave with border cells among them takes the clamped form for all its unit cells (it is the same
+  // 32 pixels for an interior cell), instead of running both forms one after the other
+  const bool allInterior = __ballot(unit && !interior) == 0ull;
+  if (interior && allInterior) {
     // the cell and its ring of neighbours lie inside the buffer: nothing is clamped, so the 12 row segments are
     // the cell's own address plus wave-uniform strides, and the x neighbours are immediate offsets
     const T *base = s.vox + ((size_t)zl * s.ny + c.lo[1]) * s.nx + c.lo[0];
