@@ -1036,14 +1036,14 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
   }
 }
 
-// one quad (or its two triangles): corner ids from the dense map, Q1 redirect, fused diagonal split
-template <bool TRI, bool MAP>
-__device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 V0,
-                                              u64 (&o)[TRI ? 6 : 4]) {
+// The four corners of face f of voxel (x, y, z) as vertex indices in this rank's point buffer, in the order of
+// txx:197-202: from the dense corner map (MAP) or recomputed; quirk Q1 redirects bottom corners of an aliased slice to
+// the top corners of its source slice; an index >= totV names a vertex of the rank below (Grid::extAlias): entry
+// index - totV of the plane that rank sent, whose positions stand behind this rank's own points.
+template <bool MAP>
+__device__ __forceinline__ void quad_corners(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 (&lid)[4]) {
   u32 unk;
   const int zp = alias_of(a.occ, g, a.q1, z, unk);
-  u64 lid[4], ext[4];                            // vertex index in the counted range
-  unsigned isExt = 0;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int i = kFaceCorner[f][c];
@@ -1060,23 +1060,21 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
       }
       if (hit) cz = zp + 1;
     }
-    ext[c] = 0;
-    if (cz == g.nzb + 1) {
-      // a vertex of the rank below (quirk Q1 across the slab boundary): its global id comes from the plane that rank
-      // sent, its position stands behind this rank's own points
-      const u64 j = (u64)cy * (u64)(g.nx + 1) + (u64)cx;
-      ext[c] = a.extIds[j];
-      lid[c] = a.tot->totV + j;
-      isExt |= 1u << c;
-    }
+    if (cz == g.nzb + 1) lid[c] = a.tot->totV + (u64)cy * (u64)(g.nx + 1) + (u64)cx;   // a vertex of the rank below
     // MAP: ids from the dense corner map; otherwise recomputed (kept out of the MAP instantiation: its
     // 27-row classification would cost the common kernel a quarter of its wave slots)
     else if (MAP) lid[c] = (u64)a.cmap[corner_map_index(g, cx, cy, cz)];
     else lid[c] = corner_id_generic(a, g, cx, cy, cz);
   }
+}
+
+// ... and from those indices the cell(s): global ids, and for triangles the split along the shorter diagonal of the
+// PROJECTED quad (txx:286-321; squared distances accumulated in double from the float coordinates, ties -> first form)
+template <bool TRI>
+__device__ __forceinline__ void finish_cell(const EmitArgs &a, u64 V0, u64 totV, const u64 (&lid)[4], u64 (&o)[TRI ? 6 : 4]) {
   u64 id[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) id[c] = ((isExt >> c) & 1u) ? ext[c] : lid[c] - V0 + a.pointOffset;
+  for (int c = 0; c < 4; c++) id[c] = lid[c] >= totV ? a.extIds[lid[c] - totV] : lid[c] - V0 + a.pointOffset;
   if constexpr (!TRI) {
     o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
   } else {
@@ -1101,61 +1099,81 @@ __device__ __forceinline__ void emit_one_cell(const EmitArgs &a, const Grid &g, 
   }
 }
 
-// K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
-// (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
-template <bool TRI, bool MAP>
-__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nwords, u64 nQ) {
-  constexpr int NV = TRI ? 6 : 4;                // ids per quad
-  // a lane's NV ids are 32 or 48 contiguous bytes, a wave's 64 quads 2 or 3 KiB: staged through LDS so that the
-  // wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
-  __shared__ u64 stage[4][64 * NV];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 waveFirst = q - lane;
-  if (waveFirst >= nQ) return;                   // wave-uniform
-  const bool valid = q < nQ;
-  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0;
+// the quad that produces output q (owned range): its voxel and face, through the prefix sums
+// (all 64 lanes of the wave call this together)
+__device__ __forceinline__ bool locate_quad(const EmitArgs &a, const Grid &g, size_t nwords, u64 q, bool valid, u64 Q0, int &x,
+                                            int &y, int &z, int &f) {
   u32 r = 0;
   size_t gi;
   if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a, a.headQ, nwords, q + Q0, valid, r);
   else gi = valid ? locate_word<16>(a, nwords, q + Q0, r) : 0;
-  if (valid) {
-    int k, y, z;
-    word_coords(g, gi, k, y, z);
-    u64 F[6];
-    faces_word(a.bits, g, y, z, k, F);
-    int lo = 0, hi = 64;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      int c = 0;
+  if (!valid) return false;
+  int k;
+  word_coords(g, gi, k, y, z);
+  u64 F[6];
+  faces_word(a.bits, g, y, z, k, F);
+  int lo = 0, hi = 64;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    int c = 0;
 #pragma unroll
-      for (int f = 0; f < 6; f++) c += popc64(F[f] & lowmask(mid));
-      if ((u32)c <= r) lo = mid; else hi = mid;
-    }
-    int before = 0;
-    unsigned fm = 0;
-#pragma unroll
-    for (int f = 0; f < 6; f++) {
-      before += popc64(F[f] & lowmask(lo));
-      fm |= (unsigned)((F[f] >> lo) & 1ull) << f;
-    }
-    u64 o[NV];
-    emit_one_cell<TRI, MAP>(a, g, k * 64 + lo, y, z, select_bit8(fm, (int)r - before), V0, o);
-#pragma unroll
-    for (int i = 0; i < NV; i++) stage[wv][lane * NV + i] = o[i];
+    for (int ff = 0; ff < 6; ff++) c += popc64(F[ff] & lowmask(mid));
+    if ((u32)c <= r) lo = mid; else hi = mid;
   }
+  int before = 0;
+  unsigned fm = 0;
+#pragma unroll
+  for (int ff = 0; ff < 6; ff++) {
+    before += popc64(F[ff] & lowmask(lo));
+    fm |= (unsigned)((F[ff] >> lo) & 1ull) << ff;
+  }
+  x = k * 64 + lo;
+  f = select_bit8(fm, (int)r - before);
+  return true;
+}
+
+// a wave's NV ids per quad are 32 or 48 contiguous bytes per lane, 2 or 3 KiB per wave: staged through LDS so that the
+// wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
+template <int NV>
+__device__ __forceinline__ void store_wave_cells(u64 *stageWave, u64 *cells, u64 waveFirst, u64 nQ) {
+  const int lane = threadIdx.x & 63;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const u64 left = nQ - waveFirst;
   const unsigned nPairs = (unsigned)(left < 64 ? left : 64) * (NV / 2);      // 16-byte pieces this wave holds
-  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(stage[wv]);
-  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.cells + waveFirst * NV);
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(stageWave);
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(cells + waveFirst * NV);
 #pragma unroll
   for (int i = 0; i < NV / 2; i++) {
     const unsigned piece = i * 64 + lane;
     if (piece < nPairs) dst[piece] = src[piece];
   }
+}
+
+// K3b: one lane per quad of the owned range; runs AFTER the projection so that the triangle split
+// (txx:286-321: along the shorter diagonal of the PROJECTED quad, ties -> first form) is fused in.
+// (Which four vertices a quad joins does not depend on the projection, so the lookup half of this kernel was also
+//  run on a second stream BESIDE the walk, with a short split pass after both: the walk slowed from 1.18 to 1.52 ms
+//  while the cell pass shrank from 0.45 to 0.15 ms -- both kernels want the vector issue slots; not kept.)
+template <bool TRI, bool MAP>
+__global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nwords, u64 nQ) {
+  constexpr int NV = TRI ? 6 : 4;                // ids per quad
+  __shared__ u64 stage[4][64 * NV];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 waveFirst = q - lane;
+  if (waveFirst >= nQ) return;                   // wave-uniform
+  const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
+  int x, y, z, f;
+  if (locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f)) {
+    u64 lid[4], o[NV];
+    quad_corners<MAP>(a, g, x, y, z, f, lid);
+    finish_cell<TRI>(a, V0, totV, lid, o);
+#pragma unroll
+    for (int i = 0; i < NV; i++) stage[wv][lane * NV + i] = o[i];
+  }
+  store_wave_cells<NV>(stage[wv], a.cells, waveFirst, nQ);
 }
 
 // ---------------------------------------------------------------------------------------------
