@@ -466,6 +466,17 @@ __device__ __forceinline__ u64 created(const Neigh &n) {
 // emit a face themselves (a voxel without a face creates no corner): the sixteen loads are issued for those lanes
 // only.  Returns the word's any-face mask; the caller ANDs it into the created masks, which also wipes whatever
 // the missing carries left in bits 0 and 63.
+// bit x = inside(x-1) / inside(x+1) of a row word c, on 32-bit halves (v_alignbit + v_lshl_or: five instructions for
+// both shifted rows instead of two 64-bit shifts, two selects and two ORs); carryM / carryP are the neighbour words'
+// edge bits (0 or 1)
+__device__ __forceinline__ void shifted_rows(u64 c, u32 carryM, u32 carryP, u64 &m, u64 &p) {
+  const u32 lo = (u32)c, hi = (u32)(c >> 32);
+  const u32 mlo = (lo << 1) | carryM, mhi = __builtin_amdgcn_alignbit(hi, lo, 31);
+  const u32 plo = __builtin_amdgcn_alignbit(hi, lo, 1), phi = (hi >> 1) | (carryP << 31);
+  m = (u64)mlo | ((u64)mhi << 32);
+  p = (u64)plo | ((u64)phi << 32);
+}
+
 template <bool YZ>
 __device__ __forceinline__ u64 load_neigh(const WordPos &w, const Grid &g, Neigh &n) {
   const u64 valid = valid_mask(g, w.k);
@@ -481,26 +492,48 @@ __device__ __forceinline__ u64 load_neigh(const WordPos &w, const Grid &g, Neigh
 #pragma unroll
     for (int dy = 0; dy < 3; dy++) c[dz][dy] = w.q[w.yo[dy] + w.zo[dz]];
   const bool first = w.k == 0, last = w.k == g.W - 1;
+  const bool ragged = g.lastpos != 63;           // uniform: the last word of a row is partly filled
   const u64 lastbit = 1ull << g.lastpos;
-  const u64 wp1 = w.q[w.km], wn1 = w.q[w.kp];
-  const u64 m11 = (c[1][1] << 1) | (first ? (c[1][1] & 1ull) : (wp1 >> 63));
-  const u64 p11 = (c[1][1] >> 1) | (last ? (c[1][1] & lastbit) : (wn1 << 63));
+  const u32 *q32 = reinterpret_cast<const u32 *>(w.q);
+  // the centre row's edge bits: always (they decide whether voxel 0 / 63 emits a face)
+  const u32 wpHi11 = q32[2 * w.km + 1], wnLo11 = q32[2 * w.kp];
+  auto row = [&](u64 cc, u32 wpHi, u32 wnLo, u64 &m, u64 &p) {
+    // border clamp (I2): off the row's ends the neighbour is the end voxel itself
+    const u32 carryM = first ? ((u32)cc & 1u) : (wpHi >> 31);
+    const u32 carryP = last ? (ragged ? 0u : (u32)(cc >> 63)) : (wnLo & 1u);
+    shifted_rows(cc, carryM, carryP, m, p);
+    if (ragged && last) p |= cc & lastbit;
+  };
+  u64 m11, p11;
+  row(c[1][1], wpHi11, wnLo11, m11, p11);
   const u64 anyFace = c[1][1] & ~(m11 & p11 & c[1][0] & c[1][2] & c[0][1] & c[2][1]);
   const bool needM = (anyFace & 1ull) && !first, needP = (anyFace >> 63) && !last;
+  u32 wpHi[3][3], wnLo[3][3];
+#pragma unroll
+  for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) { wpHi[dz][dy] = 0; wnLo[dz][dy] = 0; }
+  if (needM) {
+#pragma unroll
+    for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+        if (dz != 1 || dy != 1) wpHi[dz][dy] = q32[2 * (w.yo[dy] + w.zo[dz] - 1) + 1];
+  }
+  if (needP) {
+#pragma unroll
+    for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+        if (dz != 1 || dy != 1) wnLo[dz][dy] = q32[2 * (w.yo[dy] + w.zo[dz] + 1)];
+  }
 #pragma unroll
   for (int dz = 0; dz < 3; dz++)
 #pragma unroll
     for (int dy = 0; dy < 3; dy++) {
       u64 m, p;
       if (dz == 1 && dy == 1) { m = m11; p = p11; }
-      else {
-        const u64 cc = c[dz][dy];
-        u64 wp = 0, wn = 0;
-        if (needM) wp = w.q[w.yo[dy] + w.zo[dz] - 1];
-        if (needP) wn = w.q[w.yo[dy] + w.zo[dz] + 1];
-        m = (cc << 1) | (first ? (cc & 1ull) : (wp >> 63));
-        p = (cc >> 1) | (last ? (cc & lastbit) : (wn << 63));
-      }
+      else row(c[dz][dy], wpHi[dz][dy], wnLo[dz][dy], m, p);
       n.raw[dz][dy][0] = m; n.raw[dz][dy][1] = c[dz][dy]; n.raw[dz][dy][2] = p;
     }
   return anyFace;
