@@ -154,16 +154,18 @@ __device__ __forceinline__ u64 group_or(u64 part) {
 }
 
 // Large volumes: the sweep is bound by HBM reads (6.7-7.1 TB/s for a kernel that only reads), and what costs it is
-// the 1-bit-per-voxel WRITE stream trickling out of L2 between the reads (measured, profiles/microbench: 0.78 ms
-// with write-back 32-byte stores, 0.63 ms with the stores removed).  Here a block owns whole spans of SPAN_WORDS
-// words: its four waves threshold 8 KiB trips in turn into an LDS stage, then the 32 KiB of words leave as 16-byte
-// write-through (sc1) stores in one burst: 0.71-0.72 ms.
+// (1) the 1-bit-per-voxel WRITE stream trickling out of L2 between the reads (measured, profiles/microbench: 0.78 ms
+// with write-back 32-byte stores, 0.63 ms with the stores removed) and (2) too many loads in flight: the memory side
+// runs best with about 32 KiB outstanding per CU (two workgroups of four waves with 4 KiB each: 0.62-0.66 ms) and
+// loses 5-10 % with the 128-256 KiB a full grid keeps in flight.  Here a block owns whole spans of SPAN_WORDS words:
+// its four waves threshold 4 KiB trips in turn into an LDS stage, then the 32 KiB of words leave as 16-byte
+// write-through (sc1) stores in one burst; the grid is two workgroups per CU.
 constexpr int SPAN_WORDS = 4096;
 
 template <class T>
 __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
                                                        double isoD, u32 *__restrict__ sliceOcc, int lgWordsPerSlice) {
-  constexpr int U = 8;
+  constexpr int U = 4;
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
   constexpr int TRIPS = SPAN_WORDS / (4 * U * VPL);      // trips of U KiB per wave and span
@@ -1697,8 +1699,8 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       u64 spanWords = 0;
       if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
         const u64 nspans = nwordsAll / SPAN_WORDS;
-        const unsigned blocks = (unsigned)(nspans < (u64)(tn.classify_grid > 0 ? tn.classify_grid : 1024)
-                                               ? nspans : (u64)(tn.classify_grid > 0 ? tn.classify_grid : 1024));
+        const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU
+        const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
         hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, w.sliceOcc, lg);
         spanWords = nspans * SPAN_WORDS;
       }
@@ -1725,6 +1727,8 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       const u64 nvec = (skew + nrows * (u64)g.nx + VPL - 1) / VPL;
       const u64 nchunks = nvec / 64;
       if (nchunks) {
+        // (the 32-KiB-in-flight geometry of the span kernel does not carry over: this loop waits for all its loads before
+        //  it computes, 0.74 ms at U4 x 1024 workgroups vs 0.745 at U8 x 2048 on 1000^3 f32)
         const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, 2048);
         hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, abase, flat, nchunks, iso,
                            (u32 *)nullptr, -1, (u64)0);

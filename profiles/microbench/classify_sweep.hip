@@ -63,27 +63,6 @@ __global__ __launch_bounds__(256) void k_read_only(const uint4 *__restrict__ src
 // STORE 1: the U*VPL words of a trip are staged through LDS and written by consecutive lanes (one store).
 // PIPE: prefetch the next trip's loads before processing the current one.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 dpp_shr_or(u32 v, int) { return v; }
-
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ u64 or_dpp64(u64 v) {
-  const u32 lo = (u32)v, hi = (u32)(v >> 32);
-  const u32 lo2 = lo | (u32)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROWMASK, 0xf, false);
-  const u32 hi2 = hi | (u32)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROWMASK, 0xf, false);
-  return (u64)lo2 | ((u64)hi2 << 32);
-}
-
-// OR over each group of LPW consecutive lanes; valid in the group's last lane
-template <int LPW>
-__device__ __forceinline__ u64 group_or(u64 part) {
-  if (LPW >= 2) part = or_dpp64<0x111, 0xf>(part);
-  if (LPW >= 4) part = or_dpp64<0x112, 0xf>(part);
-  if (LPW >= 8) part = or_dpp64<0x114, 0xf>(part);
-  if (LPW >= 16) part = or_dpp64<0x118, 0xf>(part);
-  if (LPW >= 32) part = or_dpp64<0x142, 0xa>(part);   // row_bcast:15 into rows 1 and 3
-  return part;
-}
-
 template <class T, bool NT>
 __device__ __forceinline__ void load16(Vec16<T> &r, const T *p) {
   const uint4 *src = reinterpret_cast<const uint4 *>(p);
@@ -288,7 +267,7 @@ __device__ __forceinline__ void store_words16(u64 *dst, u64 a, u64 b) {
 }
 
 template <class T, int U, int SPAN, int POLICY, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nchunks, double isoD, u64 wrapMask = ~0ull) {
+__global__ __launch_bounds__(BLOCK) void k_span_variant(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nchunks, double isoD, u64 wrapMask = ~0ull) {
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
   constexpr int WAVES = BLOCK / 64;
@@ -380,30 +359,36 @@ int main(int argc, char **argv) {
     fflush(stdout);
   };
   // reference result with the product kernel
-  hipLaunchKernelGGL((k_classify_flat<float, 8, true>), dim3(2048), dim3(256), 0, 0, vox, bitsRef, nchunks, 0.5, occ, lg);
+  hipLaunchKernelGGL((k_classify_flat<float, 8, true>), dim3(2048), dim3(256), 0, 0, vox, bitsRef, nchunks, 0.5, occ, lg, (u64)0);
   CK(hipDeviceSynchronize());
 
   report("read-only U8 nt grid 2048", T.run([&] { hipLaunchKernelGGL((k_read_only<8, true>), dim3(2048), dim3(256), 0, 0, (const uint4 *)vox, nchunks, diff); }, reps), false);
-  report("product grid 2048", T.run([&] { hipLaunchKernelGGL((k_classify_flat<float, 8, true>), dim3(2048), dim3(256), 0, 0, vox, bitsVar, nchunks, 0.5, occ, lg); }, reps), true);
-#define SP(U, SPAN, POLICY, GRID)                                                                                                \
+  report("product grid 2048", T.run([&] { hipLaunchKernelGGL((k_classify_flat<float, 8, true>), dim3(2048), dim3(256), 0, 0, vox, bitsVar, nchunks, 0.5, occ, lg, (u64)0); }, reps), true);
+#define SPB(U, SPAN, BLOCK, GRID)                                                                                                \
   {                                                                                                                              \
     char nm[96];                                                                                                                 \
-    snprintf(nm, sizeof nm, "span U%d span %d policy %d grid %d (flush %d KiB)", U, SPAN, POLICY, GRID, 4 * SPAN * U * 4 * 8 / 1024); \
-    report(nm, T.run([&] { hipLaunchKernelGGL((k_classify_span<float, U, SPAN, POLICY, 256>), dim3(GRID), dim3(256), 0, 0, vox, bitsVar, nchunks, 0.5); }, reps), true); \
+    snprintf(nm, sizeof nm, "span U%d span %d block %d grid %d (flush %d KiB)", U, SPAN, BLOCK, GRID, (BLOCK / 64) * SPAN * U * 4 * 8 / 1024); \
+    report(nm, T.run([&] { hipLaunchKernelGGL((k_span_variant<float, U, SPAN, 3, BLOCK>), dim3(GRID), dim3(BLOCK), 0, 0, vox, bitsVar, nchunks, 0.5); }, reps), true); \
   }
-  SP(8, 32, 2, 1024)
-  SP(8, 32, 3, 1024)
-  SP(8, 32, 4, 1024)
-  SP(8, 32, 5, 1024)
-  SP(8, 32, 6, 1024)
-  SP(8, 16, 3, 2048)
-  SP(8, 16, 3, 1024)
-  SP(8, 8, 3, 2048)
-  SP(8, 4, 3, 2048)
-  SP(8, 32, 3, 2048)
-  SP(8, 32, 3, 512)
-  SP(4, 32, 3, 2048)
-  SP(4, 64, 3, 1024)
+  SPB(4, 64, 256, 512)
+  SPB(4, 64, 256, 768)
+  SPB(4, 64, 256, 1024)
+  SPB(4, 32, 512, 256)
+  SPB(4, 32, 512, 512)
+  SPB(2, 128, 256, 512)
+  SPB(2, 128, 256, 1024)
+  SPB(2, 128, 256, 1536)
+  SPB(2, 64, 512, 512)
+  SPB(4, 16, 1024, 256)
+  SPB(4, 128, 128, 1024)
+  SPB(4, 128, 128, 768)
+  SPB(8, 32, 256, 256)
+  SPB(4, 64, 256, 512)
+  SPB(6, 32, 256, 256)
+  SPB(6, 32, 256, 512)
+  SPB(3, 64, 256, 512)
+  SPB(3, 64, 256, 768)
+  SPB(5, 32, 256, 512)
   report("read-only U8 nt grid 2048 (again)", T.run([&] { hipLaunchKernelGGL((k_read_only<8, true>), dim3(2048), dim3(256), 0, 0, (const uint4 *)vox, nchunks, diff); }, reps), false);
   return 0;
 }
