@@ -50,6 +50,8 @@ struct cuberille_ctx {
   std::string err;
   DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, totals, points, cells, cmap, headV, headQ, vqueue;
   Totals *hostTotals = nullptr;          // pinned
+  uint32_t *hostOcc = nullptr;           // pinned mirror of the per-slice occupancy of the last slab count
+  size_t hostOccCap = 0;
   hipEvent_t ev[8] = {};
   Tuning tune;                           // development switches (cuberille_debug_set_option)
   // overlapped ingestion (cuberille_extract_host): pinned staging ring and a copy stream
@@ -189,6 +191,7 @@ void cuberille_destroy(cuberille_ctx *c) {
                     &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
+  if (c->hostOcc) (void)hipHostFree(c->hostOcc);
   for (int i = 0; i < 2; i++) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
     if (c->stageFree[i]) (void)hipEventDestroy(c->stageFree[i]);
@@ -352,6 +355,17 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
   HIP_TRY(c, launch_count(w, g, c->nwords, c->prm.q1, s));
   HIP_TRY(c, hipEventRecord(c->ev[2], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
+  if (c->slabMode) {
+    // the slab status the multi-GPU driver asks for next rides in the same synchronisation
+    if (c->hostOccCap < (size_t)g.nzb) {
+      if (c->hostOcc) (void)hipHostFree(c->hostOcc);
+      c->hostOcc = nullptr;
+      c->hostOccCap = 0;
+      HIP_TRY(c, hipHostMalloc((void **)&c->hostOcc, (size_t)g.nzb * sizeof(uint32_t), hipHostMallocDefault));
+      c->hostOccCap = (size_t)g.nzb;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->hostOcc, w.sliceOcc, (size_t)g.nzb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(c, hipStreamSynchronize(s));
   c->tot = *c->hostTotals;
   // quirk Q1 reaching below this slab: certain when the source slice is in the halo (the emit then insists on
@@ -631,15 +645,13 @@ int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, co
 
 int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
   if (!c || !out) return CUBERILLE_ERR_ARGUMENT;
-  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no counted volume on this context");
-  HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<uint32_t> occ((size_t)c->g.nzb);
-  HIP_TRY(c, hipMemcpyAsync(occ.data(), c->occ.p, occ.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((!c->counted && !c->haveMesh) || !c->slabMode || !c->hostOcc)
+    return fail(c, CUBERILLE_ERR_STATE, "no counted slab on this context");
   out->alias_source_below_buffer = c->aliasBelowBuffer ? 1 : 0;
+  out->reserved = 0;
   out->lowest_occupied_z = out->highest_occupied_z = -1;
   for (int z = c->g.oz0; z < c->g.oz1; z++)
-    if (occ[(size_t)z]) {
+    if (c->hostOcc[(size_t)z]) {
       if (out->lowest_occupied_z < 0) out->lowest_occupied_z = c->g.zglob0 + z;
       out->highest_occupied_z = c->g.zglob0 + z;
     }

@@ -924,7 +924,7 @@ def test_extract_host_overlapped_upload_equals_resident_volume(pkg, extractor):
         del dev, vox, a, b
 
 
-def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir):
+def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
     import sys
     import torch
     import torch.distributed as dist
@@ -941,6 +941,8 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir):
         nz, ny, nx = vox.shape
         prm = pkg.make_params(iso, **kw)
         ex = pkg.Extractor(0)
+        for o in options:
+            ex.debug_option(o, 1)
         sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.from_numpy(vox[:1]).dtype, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vox[sh.z0:sh.z1]).cuda()      # owned slices only
@@ -954,7 +956,8 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["two_voxels_empty_rank_between", "source_in_the_halo", "marschner_lobb_stacked"])
+@pytest.mark.parametrize("case", ["two_voxels_empty_rank_between", "source_in_the_halo", "source_in_the_halo_no_corner_map",
+                                  "marschner_lobb_stacked"])
 def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case):
     """Quirk Q1 (txx:139-141 before 156-161) when the run of empty slices contains a slab boundary: the rank above
     re-uses vertices the rank below created.  Real processes over gloo on this box's GPU: the source slice's inside
@@ -969,7 +972,7 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         vox[10, 4, 3] = 255
         vox[40, 3, 3] = 255
         iso, world = 128, 3
-    elif case == "source_in_the_halo":
+    elif case.startswith("source_in_the_halo"):
         rng = np.random.default_rng(3)
         vox = np.zeros((40, 12, 70), dtype=np.uint8)        # cut at 20; slices 16..21 empty, source slice 15 in the halo
         vox[8:16] = (rng.random((8, 12, 70)) < 0.3) * 255
@@ -987,7 +990,8 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_q1_worker, args=(world, port, str(tmp_path / "vol.npy"), iso, kw, str(tmp_path)), nprocs=world, join=True)
+    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ()
+    mp.spawn(_q1_worker, args=(world, port, str(tmp_path / "vol.npy"), iso, kw, str(tmp_path), options), nprocs=world, join=True)
 
     class M:
         pass
