@@ -779,7 +779,7 @@ struct EmitArgs {
   u64 *cells;          // 4 ids per quad, or 2 x 3 ids per quad when triangulating
   u64 pointOffset;     // global id of this rank's first point
   u32 *cmap;           // dense lattice-corner -> vertex index map, or null (see corner_map_index)
-  const u32 *headV, *headQ;   // word producing output 64*i (k_heads), or null
+  const u32 *headV, *headQ;   // word producing output 64*i (k_heads_search), or null
   const u64 *extIds;   // Grid::extAlias: global ids of the top-plane corners of the source slice, dense (nx+1) x (ny+1);
                        // their positions stand behind this rank's own points, from index totV on
 };

@@ -35,39 +35,62 @@ def buffer_range(global_nz, z0, z1, halo=HALO):
     return max(z0 - halo, 0), min(z1 + halo, int(global_nz))
 
 
-def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO):
+def halo_transfers(global_nz, world, rank, halo=HALO):
+    """The point-to-point transfers of one halo exchange as this rank sees them: (recvs, sends), each a list of
+    (peer, z_first, z_last_exclusive) in global slices.  A rank needs [z0 - halo, z0) and [z1, z1 + halo) clipped to
+    the volume; every slice of that comes from the rank that owns it -- the two neighbours when the slabs are at least
+    `halo` thick, more ranks when they are thinner (thin slabs, long walks)."""
+    ranges = [slab_range(global_nz, world, r) for r in range(world)]
+    bufs = [buffer_range(global_nz, a, b, halo) for a, b in ranges]
+
+    def needs(r):                                   # the two halo parts of rank r
+        (a, b), (lo, hi) = ranges[r], bufs[r]
+        return [(lo, a), (b, hi)]
+    recvs, sends = [], []
+    z0, z1 = ranges[rank]
+    for s in range(world):
+        if s == rank:
+            continue
+        a, b = ranges[s]
+        for p, q in needs(rank):                    # what I need of what s owns
+            o0, o1 = max(p, a), min(q, b)
+            if o1 > o0:
+                recvs.append((s, o0, o1))
+        for p, q in needs(s):                       # what s needs of what I own
+            o0, o1 = max(p, z0), min(q, z1)
+            if o1 > o0:
+                sends.append((s, o0, o1))
+    return recvs, sends
+
+
+def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
-    Fills [lo, z0) from rank-1 and [z1, hi) from rank+1.  All ranks call it together.
+    Fills [lo, z0) and [z1, hi) from the ranks that own those slices.  All ranks call it together.
     wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
     import torch.distributed as dist
     if buf.is_cuda and dist.get_backend(group) == "gloo" and wait:
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
         host = buf.cpu()
-        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo)
+        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo, global_nz=global_nz)
         if z0 > lo:
             buf[:z0 - lo].copy_(host[:z0 - lo])
         if hi > z1:
             buf[z1 - lo:].copy_(host[z1 - lo:])
         return buf
+    if global_nz is None:
+        # callers that only know their own ranges: the classic two-neighbour exchange (slabs >= halo thick)
+        recvs = ([(rank - 1, lo, z0)] if rank > 0 and z0 > lo else []) + ([(rank + 1, z1, hi)] if rank < world - 1 and hi > z1 else [])
+        sends = ([(rank + 1, z1 - min(halo, z1 - z0), z1)] if rank < world - 1 and hi > z1 else []) + \
+                ([(rank - 1, z0, z0 + min(halo, z1 - z0))] if rank > 0 and z0 > lo else [])
+    else:
+        recvs, sends = halo_transfers(global_nz, world, rank, halo)
     ops, keep = [], []
-    nlo, nhi = z0 - lo, hi - z1                     # halo depth below / above
-    if rank > 0 and nlo > 0:
-        ops.append(dist.P2POp(dist.irecv, buf[0:nlo], rank - 1, group))
-    if rank < world - 1 and nhi > 0:
-        ops.append(dist.P2POp(dist.irecv, buf[z1 - lo:hi - lo], rank + 1, group))
-    # what the neighbours miss: the upper neighbour wants my top `its_nlo` slices, the lower my bottom ones
-    if rank < world - 1:
-        n = min(halo, z1 - z0) if nhi > 0 else 0
-        if n > 0:
-            t = buf[z1 - lo - n:z1 - lo].contiguous()
-            keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, rank + 1, group))
-    if rank > 0:
-        n = min(halo, z1 - z0) if nlo > 0 else 0
-        if n > 0:
-            t = buf[z0 - lo:z0 - lo + n].contiguous()
-            keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, rank - 1, group))
+    for peer, a, b in recvs:
+        ops.append(dist.P2POp(dist.irecv, buf[a - lo:b - lo], peer, group))
+    for peer, a, b in sends:
+        t = buf[a - lo:b - lo].contiguous()
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, peer, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
     if not wait:
         return reqs, keep
@@ -192,8 +215,8 @@ class ShardedExtractor:
                 halo = max(required_halo(make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction), params))
         self.halo = int(halo)
         self.lo, self.hi = buffer_range(self.nz, self.z0, self.z1, self.halo)
-        if world > 1 and self.z1 - self.z0 < self.halo:
-            raise ValueError("slabs thinner than the halo (%d slices) are not supported" % self.halo)
+        if world > self.nz:
+            raise ValueError("more ranks (%d) than slices (%d)" % (world, self.nz))
         self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
         self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None, None)
         self._halo_event = None
@@ -226,14 +249,15 @@ class ShardedExtractor:
                     self._halo_event = torch.cuda.Event()
                 self._vox_event.record(torch.cuda.current_stream())
                 reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
-                                            wait=False, halo=self.halo)
+                                            wait=False, halo=self.halo, global_nz=self.nz)
                 for req in reqs:
                     req.wait()                     # orders torch's current stream behind the transfer, not the host
                 self._halo_event.record(torch.cuda.current_stream())
                 self.slab.voxels_ready_event = self._vox_event.cuda_event
                 self.slab.halo_ready_event = self._halo_event.cuda_event
             else:
-                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=self.halo)
+                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=self.halo,
+                               global_nz=self.nz)
                 if buf.is_cuda:
                     torch.cuda.current_stream().synchronize()
                 self.slab.halo_ready_event = None

@@ -36,8 +36,14 @@ def _worker(rank, world, port, nz, out_dir):
         lo, hi = D.buffer_range(nz, z0, z1)
         buf = torch.full((hi - lo, ny, nx), -1.0)
         buf[z0 - lo:z1 - lo] = full[z0:z1]
-        D.exchange_halos(buf, lo, hi, z0, z1, rank, world)
-        assert torch.equal(buf, full[lo:hi]), "halo exchange did not reproduce the neighbours' slices"
+        D.exchange_halos(buf, lo, hi, z0, z1, rank, world, global_nz=nz)
+        assert torch.equal(buf, full[lo:hi]), "halo exchange did not reproduce the other ranks' slices"
+        if z1 - z0 >= D.HALO:
+            # the two-neighbour form (callers that only know their own ranges) gives the same buffer
+            buf2 = torch.full((hi - lo, ny, nx), -1.0)
+            buf2[z0 - lo:z1 - lo] = full[z0:z1]
+            D.exchange_halos(buf2, lo, hi, z0, z1, rank, world)
+            assert torch.equal(buf2, full[lo:hi])
         # counts all-gather -> exclusive prefix
         counts = D.gather_counts(100 * (rank + 1), 7 * (rank + 1), torch.device("cpu"))
         assert counts.tolist() == [[100 * (r + 1), 7 * (r + 1)] for r in range(world)]
@@ -63,8 +69,10 @@ def _worker(rank, world, port, nz, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nz", [(2, 40), (3, 50)])
+@pytest.mark.parametrize("world,nz", [(2, 40), (3, 50), (4, 18)])
 def test_halo_exchange_and_offsets_gloo(tmp_path, world, nz):
+    """(4 ranks on 18 slices: slabs of 4-5 slices, thinner than the 8-slice halo -- every rank then receives from
+    ranks beyond its neighbours.)"""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, nz, str(tmp_path)), nprocs=world, join=True)
     spans = [np.load(str(tmp_path / ("ok%d.npy" % r))) for r in range(world)]
@@ -93,6 +101,30 @@ def test_alias_plan():
     assert D.alias_plan([[0, 0, 0, -1, 0], [5, 5, 1, 60, 0]]) == []                    # nothing occupied below
     # an empty rank in between: rank 2 re-uses rank 0's vertices; rank 3 those of rank 2
     assert D.alias_plan([[5, 5, 0, 10, 0], [0, 0, 0, -1, 0], [5, 5, 1, 40, 0], [5, 5, 1, 70, 0]]) == [(2, 0, 10), (3, 2, 40)]
+
+
+def test_halo_transfers_cover_the_halo_exactly():
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from midas_journal_740_amd import distributed as D
+    for nz, world, halo in [(1024, 8, 8), (18, 4, 8), (40, 5, 22), (7, 7, 3)]:
+        sent = {}
+        for r in range(world):
+            recvs, sends = D.halo_transfers(nz, world, r, halo)
+            z0, z1 = D.slab_range(nz, world, r)
+            lo, hi = D.buffer_range(nz, z0, z1, halo)
+            got = sorted(z for _, a, b in recvs for z in range(a, b))
+            assert got == list(range(lo, z0)) + list(range(z1, hi))            # every halo slice exactly once
+            for peer, a, b in recvs:
+                pa, pb = D.slab_range(nz, world, peer)
+                assert pa <= a and b <= pb                                      # ... from the rank that owns it
+            for peer, a, b in sends:
+                sent[(r, peer, a, b)] = True
+        for r in range(world):                                                  # every receive has its send
+            for peer, a, b in D.halo_transfers(nz, world, r, halo)[0]:
+                assert (peer, r, a, b) in sent
 
 
 def test_slab_plan():

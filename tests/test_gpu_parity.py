@@ -318,12 +318,13 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,event_path", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,event_path", [(2, False), (3, False), (2, True), (6, False)])
 def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
     the concatenation of the rank meshes must be the oracle's mesh of the whole volume.  event_path: the
-    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo)."""
+    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo).  Six ranks on the
+    40 slices of silicium: slabs thinner than the 8-slice halo, every rank receives from ranks beyond its neighbours."""
     import socket
     import torch.multiprocessing as mp
     name, iso = "silicium.mha", 85
