@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 4
+#define CUBERILLE_ABI_VERSION 5
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -73,7 +73,14 @@ typedef struct {
   uint32_t max_steps;            /* m_ProjectVertexMaximumNumberOfSteps (50) */
   int32_t emulate_empty_slice_aliasing; /* 1: reproduce the two-plane lookup quirk of txx:156-161
                                            when a slice holds no inside voxel */
+  int32_t projection_variant;    /* which branch of ProjectVertexToIsoSurface: CUBERILLE_PROJECT_DEFAULT (txx:439-474, what
+                                    the reference ships), _ADVANCED (USE_ADVANCED_PROJECTION, txx:340-397) or _LINESEARCH
+                                    (USE_LINESEARCH_PROJECTION, txx:398-437) -- the last two are compiled out upstream
+                                    (h:22-23); anything else is CUBERILLE_ERR_ARGUMENT */
+  int32_t reserved;              /* 0 */
 } cuberille_params;
+
+enum { CUBERILLE_PROJECT_DEFAULT = 0, CUBERILLE_PROJECT_ADVANCED = 1, CUBERILLE_PROJECT_LINESEARCH = 2 };
 
 /* Z-slab placement for multi-GPU runs (one process per GPU).
  * NULL or all-zero means "the buffer is the whole volume". */

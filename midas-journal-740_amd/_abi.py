@@ -24,7 +24,7 @@ EXPORTS = [
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ImageDesc(C.Structure):
@@ -35,7 +35,8 @@ class ImageDesc(C.Structure):
 class Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
-                ("max_steps", C.c_uint32), ("emulate_empty_slice_aliasing", C.c_int32)]
+                ("max_steps", C.c_uint32), ("emulate_empty_slice_aliasing", C.c_int32),
+                ("projection_variant", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Slab(C.Structure):

@@ -134,6 +134,8 @@ int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox,
     if (img->dims[i] > 0x7fffffffLL) return fail(c, CUBERILLE_ERR_LIMIT, "image dimension exceeds 2^31-1");
     if (!(img->spacing[i] > 0.0)) return fail(c, CUBERILLE_ERR_ARGUMENT, "spacing must be > 0");
   }
+  if (prm->projection_variant < CUBERILLE_PROJECT_DEFAULT || prm->projection_variant > CUBERILLE_PROJECT_LINESEARCH)
+    return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown projection variant");
   return CUBERILLE_OK;
 }
 
@@ -251,6 +253,7 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
   p.triangles = prm->generate_triangles != 0;
   p.project = prm->project_vertices != 0;
   p.q1 = prm->emulate_empty_slice_aliasing != 0;
+  p.variant = prm->projection_variant;
 }
 
 // First half of a count: layout, parameters, workspace, zeroed state.  The caller then thresholds the slices

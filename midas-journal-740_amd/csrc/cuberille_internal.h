@@ -93,6 +93,7 @@ struct Params {
   double thr, step, relax;
   u32 max_steps;
   int triangles, project, q1;
+  int variant;                // CUBERILLE_PROJECT_*
 };
 
 // launchers (cuberille_kernels.hip); all asynchronous on `s`

@@ -1644,6 +1644,148 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4b: the reference's two OTHER projection branches, which it compiles out (h:22-23 set both macros to 0):
+// USE_ADVANCED_PROJECTION (txx:340-397) and USE_LINESEARCH_PROJECTION (txx:398-437).  Offered for builds of the
+// reference that switch one on; never on the default path, so they are written plainly -- one lane per vertex,
+// every interpolation replayed to the letter (zero weights skipped, stop once the weights sum to 1), IEEE sqrt and
+// divide -- and share only the gather with k_project.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct VariantCtx {
+  Sampler<T> s;
+  Geo geo;
+  bool dirIdentity, unitP2I;
+  int n[3];
+  double iso;
+};
+
+// I7 + I8: the interpolated gradient at `vertex`, normalised (txx:356-357, 408-409)
+template <class T>
+__device__ void variant_normal(const VariantCtx<T> &x, const float vertex[3], float normal[3]) {
+  const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+  Cell8 c;
+  make_cell(x.geo, x.unitP2I, x.n, p, c);
+  float G[8][3];
+  typename SiteValue<T>::type Vd[8];
+  gather_cell<T, true>(x.s, x.geo, x.dirIdentity, c, G, Vd);
+  double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+#pragma unroll
+  for (unsigned counter = 0; counter < 8; counter++) {
+    double overlap = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
+    if (overlap != 0.0 && total != 1.0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[k] += overlap * (double)G[counter][k];
+      total += overlap;
+    }
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { normal[k] = (float)acc[k]; const double e = (double)normal[k]; sq += e * e; }
+  const double norm = sqrt(sq);
+#pragma unroll
+  for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+}
+
+// I5: the interpolated pixel value at `q` (txx:368-369, 424)
+template <class T>
+__device__ double variant_value(const VariantCtx<T> &x, const float q[3]) {
+  const double p[3] = {(double)q[0], (double)q[1], (double)q[2]};
+  Cell8 c;
+  make_cell(x.geo, x.unitP2I, x.n, p, c);
+  double value = 0.0, total = 0.0;
+#pragma unroll
+  for (unsigned counter = 0; counter < 8; counter++) {
+    double overlap = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
+    if (overlap != 0.0 && total != 1.0) {
+      const T pix = x.s.at((counter & 1) ? c.hi[0] : c.lo[0], (counter & 2) ? c.hi[1] : c.lo[1], (counter & 4) ? c.hi[2] : c.lo[2]);
+      value += overlap * (double)pix;
+      total += overlap;
+    }
+  }
+  return value;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+                                                         float *__restrict__ points, u64 nPoints, u64 nGhost,
+                                                         Totals *__restrict__ tot) {
+  const int lane = threadIdx.x & 63;
+  const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned passes = 0;
+  if (idx < nPoints) {
+    VariantCtx<T> x;
+    x.s = Sampler<T>{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
+    x.geo = geo;
+    x.dirIdentity = dirIdentity != 0;
+    x.unitP2I = true;
+    for (int i = 0; i < 9; i++) x.unitP2I = x.unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
+    x.n[0] = g.nx; x.n[1] = g.ny; x.n[2] = (int)g.gnz;
+    x.iso = (double)(T)prm.iso;
+    float vertex[3] = {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
+    float normal[3];
+    if (prm.variant == CUBERILLE_PROJECT_ADVANCED) {
+      double step = prm.step;
+      unsigned numberOfSteps = 0, swaps = 0;
+      int previousi = -1;
+      for (;;) {
+        passes++;
+        variant_normal(x, vertex, normal);                                        // txx:356-357
+        float temp[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                             // txx:360-364
+          temp[0][k] = (float)((double)vertex[k] + ((double)normal[k] * +1.0 * step));
+          temp[1][k] = (float)((double)vertex[k] + ((double)normal[k] * -1.0 * step));
+        }
+        step *= prm.relax;                                                        // txx:365
+        const double d0 = fabs(variant_value(x, temp[0]) - x.iso);                // txx:368-371
+        const double d1 = fabs(variant_value(x, temp[1]) - x.iso);
+        const int i = (d0 <= d1) ? 0 : 1;                                         // txx:372
+        if (previousi < 0) previousi = i;                                         // txx:373
+        swaps += (unsigned)(previousi != i);                                      // txx:374
+#pragma unroll
+        for (int k = 0; k < 3; k++) vertex[k] = i ? temp[1][k] : temp[0][k];      // txx:375
+        if ((i ? d1 : d0) < prm.thr) break;                                       // txx:378-382
+        if (numberOfSteps++ > prm.max_steps) break;                               // txx:385-389
+        if (swaps >= 5) break;                                                    // txx:392-396
+      }
+    } else {
+      // the reference leaves bestVertex unset when no sample beats the initial 10000 (txx:404-405,437): the vertex
+      // then stays where it is, like the CPU checker
+      float best[3] = {vertex[0], vertex[1], vertex[2]};
+      double bestMetric = 10000;
+      variant_normal(x, vertex, normal);                                          // txx:408-409
+      for (double sign = -1.0; sign <= 1.0; sign += 2.0)                          // txx:412
+        for (unsigned j = 1; j < prm.max_steps / 2; j++) {                        // txx:415
+          passes++;
+          const double d = (double)j / ((double)prm.max_steps / 2.0);             // txx:418
+          float temp[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++)                                             // txx:419-422
+            temp[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * prm.step * d));
+          const double metric = fabs(variant_value(x, temp) - x.iso);             // txx:424-425
+          if (metric < bestMetric) {                                              // txx:430-434
+            bestMetric = metric;
+#pragma unroll
+            for (int k = 0; k < 3; k++) best[k] = temp[k];
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < 3; k++) vertex[k] = best[k];                            // txx:437
+    }
+    points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
+    if (idx < nGhost) passes = 0;                  // the iteration statistic counts owned vertices only
+  }
+  unsigned sum = passes;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
+  if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <class F>
@@ -1850,6 +1992,13 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
+  if (p.variant != CUBERILLE_PROJECT_DEFAULT)
+    return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
+      typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+      hipLaunchKernelGGL((k_project_variant<T>), dim3(grid_for(nPoints, 256, 0)), dim3(256), 0, s, (const T *)w.vox, g, geo, p,
+                         dirIdentity, w.points, nPoints, nGhost, w.totals);
+      return hipGetLastError();
+    });
   // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms
   // for one contiguous chunk of 256 per wave; u8 noise prefers contiguous, 2.23 vs 2.35 ms; earlier runs:
   // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)

@@ -69,9 +69,15 @@ class Mesh:
             raise _abi.CuberilleError(rc, "cannot write %s" % path)
 
 
-def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50, q1=True):
+PROJECT_DEFAULT, PROJECT_ADVANCED, PROJECT_LINESEARCH = 0, 1, 2    # include/cuberille_hip.h CUBERILLE_PROJECT_*
+
+
+def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50, q1=True,
+                variant=PROJECT_DEFAULT):
+    """variant picks the branch of ProjectVertexToIsoSurface: the shipped one (txx:439-474) or one of the two the
+    reference compiles out (USE_ADVANCED_PROJECTION txx:340-397, USE_LINESEARCH_PROJECTION txx:398-437; h:22-23)."""
     return _abi.Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                       float(relax), int(max_steps), int(bool(q1)))
+                       float(relax), int(max_steps), int(bool(q1)), int(variant), 0)
 
 
 def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
@@ -254,6 +260,7 @@ class CuberilleImageToMeshFilter:
         self._relax = 0.95
         self._max_steps = 50
         self._q1 = True
+        self._variant = PROJECT_DEFAULT           # h:22-23: both alternative branches are compiled out
         self.last_result = None
 
     # h:184 / txx:53-56
@@ -331,6 +338,13 @@ class CuberilleImageToMeshFilter:
         """Not in the reference: switches the reproduction of its quirk Q1."""
         self._q1 = bool(b)
 
+    def SetProjectionVariant(self, variant):
+        """Not in the reference's API: stands for building it with USE_ADVANCED_PROJECTION (1) or
+        USE_LINESEARCH_PROJECTION (2) set (h:22-23); 0 is what it ships."""
+        if variant not in (PROJECT_DEFAULT, PROJECT_ADVANCED, PROJECT_LINESEARCH):
+            raise ValueError("projection variant must be 0, 1 or 2")
+        self._variant = int(variant)
+
     def Update(self):
         if self._input is None:
             # the ITK pipeline throws for a missing required input (txx:33)
@@ -341,7 +355,7 @@ class CuberilleImageToMeshFilter:
         if self._step < 0.0:                      # txx:82-85, sticky like the reference (quirk Q3)
             self._step = max(vol.spacing) * 0.25
         prm = make_params(self._iso, self._triangles, self._project, self._threshold, self._step, self._relax,
-                          self._max_steps, self._q1)
+                          self._max_steps, self._q1, self._variant)
         self.last_result = self._extractor.extract_host(vol, prm)
         self._output = self._extractor.download()
 

@@ -11,6 +11,16 @@
 #ifndef __itkCuberilleImageToMeshFilter_h
 #define __itkCuberilleImageToMeshFilter_h
 
+// The reference fixes both at 0 (h:22-23), compiling the two alternative branches of ProjectVertexToIsoSurface out
+// (txx:340-437).  A build of the reference with one of them switched on is matched by defining the same macro
+// before this header is included: the choice travels as cuberille_params::projection_variant.
+#ifndef USE_ADVANCED_PROJECTION
+#define USE_ADVANCED_PROJECTION 0
+#endif
+#ifndef USE_LINESEARCH_PROJECTION
+#define USE_LINESEARCH_PROJECTION 0
+#endif
+
 #include "itkMacro.h"
 #include "itkMesh.h"
 #include "itkImageToMeshFilter.h"

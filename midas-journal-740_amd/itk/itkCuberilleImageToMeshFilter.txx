@@ -355,6 +355,13 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   prm.relaxation = m_ProjectVertexStepLengthRelaxationFactor;
   prm.max_steps = m_ProjectVertexMaximumNumberOfSteps;
   prm.emulate_empty_slice_aliasing = 1;
+  // same precedence as the reference's #if / #elif (txx:340,398)
+  prm.projection_variant = USE_ADVANCED_PROJECTION ? CUBERILLE_PROJECT_ADVANCED
+                         : (USE_LINESEARCH_PROJECTION ? CUBERILLE_PROJECT_LINESEARCH : CUBERILLE_PROJECT_DEFAULT);
+  prm.reserved = 0;
+  if (hostWalk && m_ProjectVerticesToIsoSurface && prm.projection_variant != CUBERILLE_PROJECT_DEFAULT)
+    itkExceptionMacro(<< "USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION are only offered with the default "
+                         "LinearInterpolateImageFunction");
 
   if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));

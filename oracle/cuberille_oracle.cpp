@@ -293,13 +293,85 @@ struct Filter {
     }
   }
 
+  // txx:340-397, the USE_ADVANCED_PROJECTION branch (compiled out upstream, h:22): every pass steps BOTH ways along
+  // the normal and keeps the end that is closer to the iso value; stops within the threshold, out of steps, or after
+  // five passes that chose the other side than the first pass did
+  void ProjectVertexAdvanced(float vertex[3]) {
+    bool done = false;
+    double step = step_length;
+    unsigned int numberOfSteps = 0;
+    float temp[2][3];
+    double value[2], diff[2];
+    unsigned int i, swaps = 0;
+    int previousi = -1;
+    while (!done) {
+      iters++;
+      const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+      float normal[3];
+      interpolate_gradient(im.g, grad.data(), p, normal);                     // txx:356
+      normalize(normal);                                                      // txx:357
+      for (int k = 0; k < 3; k++) {                                           // txx:360-364
+        temp[0][k] = (float)((double)vertex[k] + ((double)normal[k] * +1.0 * step));
+        temp[1][k] = (float)((double)vertex[k] + ((double)normal[k] * -1.0 * step));
+      }
+      step *= prm.relaxation;                                                 // txx:365
+      for (int e = 0; e < 2; e++) {                                           // txx:368-371
+        const double q[3] = {(double)temp[e][0], (double)temp[e][1], (double)temp[e][2]};
+        value[e] = interpolate(im, q);
+        diff[e] = std::fabs(value[e] - (double)iso);
+      }
+      i = (diff[0] <= diff[1]) ? 0 : 1;                                       // txx:372
+      if (previousi < 0) previousi = (int)i;                                  // txx:373
+      swaps += (unsigned int)(previousi != (int)i);                           // txx:374
+      for (int k = 0; k < 3; k++) vertex[k] = temp[i][k];                     // txx:375
+      done |= diff[i] < prm.distance_threshold;                               // txx:378
+      if (done) { stop_thr++; break; }
+      done |= numberOfSteps++ > prm.max_steps;                                // txx:385
+      if (done) { stop_steps++; break; }
+      done |= (swaps >= 5);                                                   // txx:392
+      if (done) break;
+    }
+  }
+
+  // txx:398-437, the USE_LINESEARCH_PROJECTION branch (compiled out upstream, h:23): one normal, MaximumNumberOfSteps/2 - 1
+  // samples on either side of the vertex out to the step length, the sample closest to the iso value wins.
+  // Upstream leaves bestVertex uninitialised when no sample beats the initial 10000 (or there is no sample at all);
+  // here the vertex then stays where it is.
+  void ProjectVertexLineSearch(float vertex[3]) {
+    float normal[3], bestVertex[3] = {vertex[0], vertex[1], vertex[2]};
+    double bestMetric = 10000;
+    const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+    interpolate_gradient(im.g, grad.data(), p, normal);                       // txx:408
+    normalize(normal);                                                        // txx:409
+    for (double sign = -1.0; sign <= 1.0; sign += 2.0) {                      // txx:412
+      for (unsigned int j = 1; j < prm.max_steps / 2; j++) {                  // txx:415
+        iters++;
+        const double d = (double)j / ((double)prm.max_steps / 2.0);           // txx:418
+        float temp[3];
+        for (int k = 0; k < 3; k++)                                           // txx:419-422
+          temp[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step_length * d));
+        const double q[3] = {(double)temp[0], (double)temp[1], (double)temp[2]};
+        const double metric = std::fabs(interpolate(im, q) - (double)iso);    // txx:424-425
+        if (metric < bestMetric) {                                            // txx:430-434
+          bestMetric = metric;
+          for (int k = 0; k < 3; k++) bestVertex[k] = temp[k];
+        }
+      }
+    }
+    for (int k = 0; k < 3; k++) vertex[k] = bestVertex[k];                    // txx:437
+  }
+
   // txx:256-276
   void AddVertex(uint64_t &id, const idx_t index[3]) {
     float vertex[3];
     index_to_point(im.g, index, vertex);                                      // txx:266
     for (int k = 0; k < 3; k++)                                               // txx:268-270
       vertex[k] = (float)((double)vertex[k] - (im.g.spacing[k] / 2.0));
-    if (prm.project_vertices) ProjectVertexToIsoSurface(vertex);              // txx:271-274
+    if (prm.project_vertices) {                                               // txx:271-274
+      if (prm.projection_variant == 1) ProjectVertexAdvanced(vertex);
+      else if (prm.projection_variant == 2) ProjectVertexLineSearch(vertex);
+      else ProjectVertexToIsoSurface(vertex);
+    }
     if (points.size() < 3 * (id + 1)) points.resize(3 * (id + 1));
     std::memcpy(&points[3 * id], vertex, sizeof(vertex));                     // txx:275
     id++;

@@ -51,6 +51,9 @@ typedef struct {
   uint32_t max_steps;            /* txx:40 */
   int32_t gradient_threads;      /* threads of the whole-image gradient pre-pass (ITK's is multi-threaded) */
   int32_t faithful_cells;        /* 1: one heap object per cell like txx:311,318,327 (cpu_baseline timing) */
+  int32_t projection_variant;    /* 0: the default branch (txx:439-474); 1: USE_ADVANCED_PROJECTION (txx:340-397);
+                                    2: USE_LINESEARCH_PROJECTION (txx:398-437) -- both compiled out upstream (h:22-23) */
+  int32_t reserved;
 } oracle_params;
 
 typedef struct {

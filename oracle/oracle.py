@@ -27,7 +27,8 @@ class _Image(C.Structure):
 class _Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
-                ("max_steps", C.c_uint32), ("gradient_threads", C.c_int32), ("faithful_cells", C.c_int32)]
+                ("max_steps", C.c_uint32), ("gradient_threads", C.c_int32), ("faithful_cells", C.c_int32),
+                ("projection_variant", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _Mesh(C.Structure):
@@ -88,11 +89,12 @@ class OracleMesh:
 
 def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50,
         spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), gradient_threads=1,
-        faithful_cells=False):
-    """Run the restated reference sweep on `vol` ([z,y,x] numpy array)."""
+        faithful_cells=False, variant=0):
+    """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  variant: 0 the default projection,
+    1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches."""
     img, keep = _image(vol, spacing, origin, direction)
     prm = _Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)))
+                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), 0)
     mesh = _Mesh()
     rc = lib().cuberille_oracle_run(C.byref(img), C.byref(prm), C.byref(mesh))
     if rc != 0:

@@ -999,3 +999,107 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
     m = M()
     m.points, m.cells = np.load(str(tmp_path / "gp.npy")), np.load(str(tmp_path / "gc.npy"))
     assert_same_mesh(m, ref)
+
+
+# ---- the reference's two compiled-out projection branches (h:22-23; txx:340-397, 398-437) -----------------------------
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_compiled_out_projection_branches_match_oracle(pkg, oracle, extractor, volumes, variant):
+    """cuberille_params::projection_variant = ADVANCED / LINESEARCH against the oracle's restatement of the same
+    branch (itself checked against a second restatement in tests/test_oracle.py): data volumes, every pixel type on
+    ragged noise, anisotropic rotated geometry, non-finite voxels, max_steps with no or one sample per side."""
+    for name, iso in [("nucleon.mha", 128), ("fuel.mha", 15), ("blob2.mha", 200)]:
+        vol = volumes(name)
+        for tri in (0, 1):
+            kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=24)
+            want = oracle.run(vol.voxels, iso, variant=variant, **kw)
+            got = run_gpu(pkg, extractor, vol, iso, variant=variant, **kw)
+            assert_same_mesh(got, want)
+            assert int(extractor.result.proj_iterations) == want.info["proj_iterations"]
+    rng = np.random.default_rng(40 + variant)
+    th = 0.3
+    rot = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    for dtype in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64):
+        shape = (7, 9, 70)
+        if np.dtype(dtype).kind == "f":
+            vox = rng.normal(0.0, 1.0, size=shape)
+            vox[rng.random(shape) < 0.2] = 0.0
+            bad = rng.random(shape)
+            vox[bad < 0.01] = np.inf
+            vox[(bad >= 0.01) & (bad < 0.02)] = np.nan
+            vox, iso = vox.astype(dtype), 0.25
+        else:
+            info = np.iinfo(dtype)
+            vox = rng.integers(max(info.min, -100), min(info.max, 100), size=shape, endpoint=True).astype(dtype)
+            iso = 10
+        for geo in ({}, dict(spacing=(0.7, 1.3, 2.1), origin=(-3.0, 4.0, 0.5), direction=rot)):
+            for max_steps in (3, 4, 9, 50):
+                kw = dict(triangles=1, project=1, threshold=0.05, step=0.25, relax=0.9, max_steps=max_steps)
+                want = oracle.run(vox, iso, variant=variant, **kw, **geo)
+                got = run_gpu(pkg, extractor, pkg.Volume(vox, **geo), iso, variant=variant, **kw)
+                assert_same_mesh(got, want)
+                assert int(extractor.result.proj_iterations) == want.info["proj_iterations"]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_compiled_out_projection_branches_in_slabs(pkg, oracle, extractor, volumes, variant):
+    """Both branches travel no farther than the shipped walk, so cuberille_required_halo covers them: slabs with
+    exactly that halo concatenate to the oracle's whole-volume mesh."""
+    import torch
+    vol = volumes("fuel.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=30)
+    want = oracle.run(vol.voxels, 15, variant=variant, **kw)
+    prm = pkg.make_params(15, variant=variant, **kw)
+    below, above = pkg.required_halo(pkg.make_desc(vol.voxels.dtype, vol.dims), prm)
+    pts, cells, poff, iters = [], [], 0, 0
+    for a, b in zip([0, 21, 22, 40], [21, 22, 40, nz]):
+        lo, hi = max(a - below, 0), min(b + above, nz)
+        slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+        n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo)), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        res = extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+        iters += int(extractor.result.proj_iterations)
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), want)
+    assert iters == want.info["proj_iterations"]
+
+
+def test_unknown_projection_variant_is_refused(pkg, extractor, volumes):
+    vol = volumes("blob0.mha")
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.extract_host(vol, pkg.make_params(200, variant=3))
+    assert e.value.code == pkg._abi.ERR_ARGUMENT
+    extractor.extract_host(vol, pkg.make_params(200))        # the context stays usable
+
+
+@pytest.mark.parametrize("variant,suffix", [(1, "advanced"), (2, "linesearch")])
+def test_reference_driver_built_with_a_projection_macro(oracle, volumes, ctest_cases, tmp_path, variant, suffix):
+    """The reference's CuberilleTest01.cxx compiled unchanged with -DUSE_ADVANCED_PROJECTION=1 /
+    -DUSE_LINESEARCH_PROJECTION=1 against the drop-in header: the macro reaches the device as projection_variant."""
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "CuberilleTest01_" + suffix)
+    if not os.path.exists(exe):
+        pytest.skip("drop-in driver binary not built (needs /root/reference at build time)")
+    ran = 0
+    for c in ctest_cases:
+        if not c["project"] or ran >= 4:
+            continue
+        ran += 1
+        out = str(tmp_path / (c["name"] + ".vtk"))
+        args = [exe, "Test01", os.path.join(GOLDEN, "data", c["input"]), out, str(c["iso"]), str(c["points"]),
+                str(c["cells"]), str(c["triangles"]), str(c["project"]), repr(c["threshold"]), repr(c["step"]),
+                repr(c["relax"]), str(c["max_steps"])]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (c["name"], r.stdout[-400:], r.stderr[-400:])
+        pts, cells = _read_vtk_polydata(out)
+        ref = oracle.run(volumes(c["input"]).voxels, c["iso"], c["triangles"], c["project"], c["threshold"], c["step"],
+                         c["relax"], c["max_steps"], variant=variant)
+        shipped = oracle.run(volumes(c["input"]).voxels, c["iso"], c["triangles"], c["project"], c["threshold"],
+                             c["step"], c["relax"], c["max_steps"])
+        assert np.array_equal(cells, ref.cells.astype(np.int64)), c["name"]
+        np.testing.assert_allclose(pts, ref.points, rtol=1e-6, atol=0)
+        assert not np.allclose(pts, shipped.points, rtol=1e-6, atol=0)      # it is not the shipped branch
+    assert ran > 0

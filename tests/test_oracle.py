@@ -182,3 +182,127 @@ def test_oracle_reproduces_bench_field_digests(pkg, oracle):
         assert (len(m.points), len(m.cells), m.info["proj_iterations"]) == (r["points"], r["cells"], r["proj_iterations"])
         assert hashlib.sha256(point_bytes(m.points)).hexdigest() == r["points_sha256"]
         assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"]
+
+
+# ---- the two projection branches the reference compiles out (h:22-23; txx:340-397 and 398-437) ----------------------
+# No fixture of the reference covers them (its CTest table only runs the shipped branch), so the C++ restatement is
+# checked against a second, independent restatement: the control flow below in plain Python floats (IEEE double, like
+# the reference's arithmetic) over the two primitives the contract tests above pin (I5 interpolation, I6 gradient).
+
+def _f32(v):
+    return float(np.float32(v))
+
+
+def _py_normal(oracle, vol, p):
+    n = vol.shape[::-1]
+    lo, hi, d = [], [], []
+    for k in range(3):
+        b = np.floor(p[k])
+        d.append(p[k] - b)
+        lo.append(int(min(max(b, 0), n[k] - 1)))
+        hi.append(int(min(max(b + 1, 0), n[k] - 1)))
+    acc, total = [0.0, 0.0, 0.0], 0.0
+    for counter in range(8):
+        overlap, ni = 1.0, []
+        for k in range(3):
+            if counter & (1 << k):
+                ni.append(hi[k]); overlap *= d[k]
+            else:
+                ni.append(lo[k]); overlap *= 1.0 - d[k]
+        if overlap:
+            g = oracle.gradient_at_index(vol, tuple(ni))
+            for k in range(3):
+                acc[k] += overlap * float(g[k])
+            total += overlap
+        if total == 1.0:
+            break
+    nrm = [_f32(a) for a in acc]
+    norm = float(np.sqrt(np.float64(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2])))
+    with np.errstate(all="ignore"):
+        return [_f32(np.float64(v) / np.float64(norm)) for v in nrm]
+
+
+def _py_advanced(oracle, vol, iso, v, thr, step, relax, max_steps):
+    v = [float(c) for c in v]
+    number_of_steps, swaps, previous, passes = 0, 0, -1, 0
+    while True:
+        passes += 1
+        nrm = _py_normal(oracle, vol, v)
+        temp = [[_f32(v[k] + (nrm[k] * s * step)) for k in range(3)] for s in (+1.0, -1.0)]
+        step *= relax
+        diff = [abs(oracle.interpolate(vol, tuple(t)) - iso) for t in temp]
+        i = 0 if diff[0] <= diff[1] else 1
+        if previous < 0:
+            previous = i
+        swaps += int(previous != i)
+        v = temp[i]
+        if diff[i] < thr:
+            break
+        number_of_steps += 1
+        if number_of_steps - 1 > max_steps:
+            break
+        if swaps >= 5:
+            break
+    return v, passes
+
+
+def _py_linesearch(oracle, vol, iso, v, step, max_steps):
+    v = [float(c) for c in v]
+    nrm = _py_normal(oracle, vol, v)
+    best, best_metric, passes = list(v), 10000.0, 0
+    for sign in (-1.0, 1.0):
+        for j in range(1, max_steps // 2):
+            passes += 1
+            d = float(j) / (float(max_steps) / 2.0)
+            temp = [_f32(v[k] + (nrm[k] * sign * step * d)) for k in range(3)]
+            metric = abs(oracle.interpolate(vol, tuple(temp)) - iso)
+            if metric < best_metric:
+                best_metric, best = metric, temp
+    return best, passes
+
+
+def _small_field():
+    n = 11
+    z, y, x = np.meshgrid(*(np.arange(n, dtype=np.float64),) * 3, indexing="ij")
+    c = (n - 1) / 2
+    return (3.3 - np.sqrt((x - c - 0.25) ** 2 + (y - c - 0.125) ** 2 + (z - c + 0.3) ** 2)
+            + 0.15 * np.sin(1.7 * x) * np.cos(1.3 * y + z)).astype(np.float32)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_compiled_out_projection_branches_against_python_restatement(oracle, variant):
+    vol = _small_field()
+    kw = dict(threshold=0.01, step=0.3, relax=0.9, max_steps=14)
+    flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+    got = oracle.run(vol, 0.0, triangles=False, project=True, variant=variant, **kw)
+    assert np.array_equal(got.cells, flat.cells)              # which vertices a quad joins never depends on the walk
+    passes = 0
+    for i, v in enumerate(flat.points):
+        if variant == 1:
+            want, n = _py_advanced(oracle, vol, 0.0, v, kw["threshold"], kw["step"], kw["relax"], kw["max_steps"])
+        else:
+            want, n = _py_linesearch(oracle, vol, 0.0, v, kw["step"], kw["max_steps"])
+        passes += n
+        assert np.array_equal(np.asarray(want, dtype=np.float32).view(np.uint32), got.points[i].view(np.uint32)), i
+    assert got.info["proj_iterations"] == passes
+
+
+def test_compiled_out_projection_branches_properties(oracle):
+    n = 32
+    z, y, x = np.meshgrid(*(np.arange(n, dtype=np.float64),) * 3, indexing="ij")
+    c = (n - 1) / 2
+    sdf = (11.0 - np.sqrt((x - c - 0.25) ** 2 + (y - c - 0.125) ** 2 + (z - c) ** 2)).astype(np.float32)
+    kw = dict(triangles=True, threshold=0.02, step=0.25, relax=0.95, max_steps=50)
+    flat = oracle.run(sdf, 0.0, project=False, **kw)
+    centre = np.array([c + 0.25, c + 0.125, c], dtype=np.float32)
+    adv = oracle.run(sdf, 0.0, project=True, variant=1, **kw)
+    r = np.sqrt(((adv.points - centre) ** 2).sum(1))
+    assert np.abs(r - 11.0).max() < 0.3 and np.abs(r - 11.0).mean() < 0.06
+    assert adv.info["proj_iterations"] <= len(adv.points) * (kw["max_steps"] + 2)
+    ls = oracle.run(sdf, 0.0, project=True, variant=2, **kw)
+    moved = np.sqrt(((ls.points.astype(np.float64) - flat.points) ** 2).sum(1))
+    assert moved.max() < kw["step"] + 1e-6                    # d = j / (max_steps / 2) stays below 1 (txx:415-418)
+    assert ls.info["proj_iterations"] == len(ls.points) * 2 * (kw["max_steps"] // 2 - 1)
+    # no sample at all (max_steps < 4): the vertex stays where it is
+    none = oracle.run(sdf, 0.0, project=True, variant=2, **dict(kw, max_steps=3))
+    assert np.array_equal(none.points.view(np.uint32), flat.points.view(np.uint32))
