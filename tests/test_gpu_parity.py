@@ -279,7 +279,7 @@ def test_reference_driver_unchanged(pkg, extractor, oracle, volumes, ctest_cases
     assert r.returncode != 0 and "Expected mesh with 9 points" in r.stderr
 
 
-def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
+def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0.24):
     import os
     if event_path:
         os.environ["CUBERILLE_FORCE_EVENT_PATH"] = "1"
@@ -298,10 +298,11 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
         vol = pkg.read_mha(os.path.join(GOLDEN, "data", name))
         nx, ny, nz = vol.dims
         ex = pkg.Extractor(0)
-        sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True)
+        prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=0.95, max_steps=100)
+        sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm)
+        assert sh.halo == (8 if step == 0.24 else 13)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()   # owned slices only
-        prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
         sh.extract(buf, prm)
         m = ex.download()
         np.save(os.path.join(out_dir, "p%d.npy" % rank), m.points)
@@ -318,13 +319,14 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,event_path", [(2, False), (3, False), (2, True), (6, False)])
-def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path):
+@pytest.mark.parametrize("world,event_path,step", [(2, False, 0.24), (3, False, 0.24), (2, True, 0.24), (4, False, 0.5)])
+def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
     the concatenation of the rank meshes must be the oracle's mesh of the whole volume.  event_path: the
-    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo).  Six ranks on the
-    40 slices of silicium: slabs thinner than the 8-slice halo, every rank receives from ranks beyond its neighbours."""
+    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo).  Four ranks on the
+    40 slices of silicium with a step of 0.5: 10-slice slabs under a 13-slice halo, so every rank receives from ranks
+    beyond its neighbours (four ranks, not more: the box allows six processes on its GPU, this one included)."""
     import socket
     import torch.multiprocessing as mp
     name, iso = "silicium.mha", 85
@@ -332,10 +334,10 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path, step), nprocs=world, join=True)
     pts = np.concatenate([np.load(str(tmp_path / ("p%d.npy" % r))) for r in range(world)])
     cells = np.concatenate([np.load(str(tmp_path / ("c%d.npy" % r))) for r in range(world)])
-    ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95,
+    ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=step, relax=0.95,
                      max_steps=100)
 
     class M:
