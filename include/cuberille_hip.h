@@ -203,7 +203,10 @@ int cuberille_debug_bits(cuberille_ctx *ctx, uint64_t *words, size_t n_words);
 int cuberille_slice_occupancy(cuberille_ctx *ctx, uint32_t *occupied, size_t n_slices);
 /* Development switches of one context (kernel variants, dropping a scratch table to exercise the fallback
  * path): name = a field of cuberille::Tuning (csrc/cuberille_internal.h), or "defaults" to reset them all.
- * Results never depend on them, only speed and memory.  Used by the parity tests and the ablation scripts. */
+ * Results never depend on them, only speed and memory.  Used by the parity tests and the ablation scripts.
+ * One more name, "fail_alloc_at" = n, is a failure drill: the n-th device allocation the CALLING THREAD makes from
+ * now on (through any context) reports out-of-memory (-1 or "defaults": off).  A required buffer then gives
+ * CUBERILLE_ERR_HIP and leaves the context usable; an optional scratch table is done without. */
 int cuberille_debug_set_option(cuberille_ctx *ctx, const char *name, int64_t value);
 /* Measurement aid for the PCIe-inclusive numbers: seconds this context's device takes to receive `bytes` from
  * pinned host memory (64 MiB copies back to back on one stream) -- the link rate cuberille_extract_host is held to. */

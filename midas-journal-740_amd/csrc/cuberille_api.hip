@@ -26,11 +26,16 @@ namespace {
 // text of the last failed cuberille_create on this thread (contexts are independent; so are their creators)
 thread_local std::string g_create_error;
 
+// Failure drill (cuberille_debug_set_option "fail_alloc_at" = n): the n-th device allocation this THREAD makes from now on
+// reports out-of-memory without touching the device; -1 = off.  Lets the tests walk every allocation-failure path.
+thread_local long long g_fail_alloc_countdown = -1;
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    if (g_fail_alloc_countdown >= 0 && g_fail_alloc_countdown-- == 0) return hipErrorOutOfMemory;
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
     // grow with head-room so that repeated calls on similar volumes do not re-allocate
     size_t want = bytes + bytes / 8 + 256;
@@ -699,7 +704,8 @@ int cuberille_debug_h2d_seconds(cuberille_ctx *c, size_t bytes, double *seconds)
 
 int cuberille_debug_set_option(cuberille_ctx *c, const char *name, int64_t value) {
   if (!c || !name) return CUBERILLE_ERR_ARGUMENT;
-  if (!std::strcmp(name, "defaults")) { c->tune = Tuning(); return CUBERILLE_OK; }
+  if (!std::strcmp(name, "defaults")) { c->tune = Tuning(); g_fail_alloc_countdown = -1; return CUBERILLE_OK; }
+  if (!std::strcmp(name, "fail_alloc_at")) { g_fail_alloc_countdown = (long long)value; return CUBERILLE_OK; }
   if (!set_opt(c->tune, name, (long long)value)) return fail(c, CUBERILLE_ERR_ARGUMENT, std::string("unknown option ") + name);
   return CUBERILLE_OK;
 }

@@ -1105,3 +1105,46 @@ def test_reference_driver_built_with_a_projection_macro(oracle, volumes, ctest_c
         np.testing.assert_allclose(pts, ref.points, rtol=1e-6, atol=0)
         assert not np.allclose(pts, shipped.points, rtol=1e-6, atol=0)      # it is not the shipped branch
     assert ran > 0
+
+
+def test_allocation_failure_drill(pkg, oracle, volumes):
+    """Every device allocation of an extraction fails once (debug option fail_alloc_at = n: the n-th allocation of this
+    thread reports out-of-memory): a required buffer gives CUBERILLE_ERR_HIP with a message and leaves the context
+    usable -- the very next call gives the oracle's mesh; an optional table (corner map, head tables, vertex-word
+    queue, flat bit stream of ragged rows) is done without and the mesh is still the oracle's."""
+    rng = np.random.default_rng(77)
+    vox = (rng.random((9, 11, 70)) < 0.3).astype(np.uint8) * 200          # ragged rows: the flat-stream scratch is in play
+    vol = pkg.Volume(vox)
+    kw = dict(triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95, max_steps=30)
+    want = oracle.run(vox, 100, **kw)
+    prm = pkg.make_params(100, **kw)
+    failed = degraded = 0
+    for n in range(40):
+        ex = pkg.Extractor(0)                                # a fresh context: nothing is allocated yet
+        try:
+            ex.debug_option("fail_alloc_at", n)
+            try:
+                ex.extract_host(vol, prm)
+                hit = False
+            except pkg._abi.CuberilleError as e:
+                assert e.code == pkg._abi.ERR_HIP and "reserve" in str(e), str(e)
+                hit = True
+            if hit:
+                failed += 1
+                ex.extract_host(vol, prm)                    # the drill has fired: this one goes through
+            assert_same_mesh(ex.download(), want)
+            # (the countdown is still armed when the extraction made fewer than n allocations)
+            ex.debug_option("fail_alloc_at", 0)
+            try:
+                ex.extract_host(pkg.Volume(np.zeros((40, 40, 200), dtype=np.uint8)), prm)   # bigger: must allocate
+                past_the_end = False
+            except pkg._abi.CuberilleError:
+                past_the_end = True
+            assert past_the_end
+            if not hit:
+                degraded += 1
+        finally:
+            ex.debug_option("defaults", 0)
+            ex.close()
+    assert failed >= 8, failed          # voxels, bits, occupancy, prefix, segment and block tables, points, cells
+    assert degraded >= 3, degraded      # optional tables skipped
