@@ -1148,3 +1148,31 @@ def test_allocation_failure_drill(pkg, oracle, volumes):
             ex.close()
     assert failed >= 8, failed          # voxels, bits, occupancy, prefix, segment and block tables, points, cells
     assert degraded >= 3, degraded      # optional tables skipped
+
+
+def test_two_contexts_on_two_threads(pkg, oracle, volumes):
+    """"Distinct contexts are independent" (include/cuberille_hip.h): two host threads, one context each (own stream,
+    own workspace), extracting different volumes at the same time; every result is the oracle's."""
+    import threading
+    cases = [("nucleon.mha", 128), ("fuel.mha", 15), ("silicium.mha", 85), ("hydrogenAtom.mha", 15)]
+    kw = dict(triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95, max_steps=40)
+    want = {name: oracle.run(volumes(name).voxels, iso, **kw) for name, iso in cases}
+    errors = []
+
+    def worker(tid):
+        try:
+            ex = pkg.Extractor(0)
+            for rep in range(12):
+                name, iso = cases[(tid + rep) % len(cases)]
+                ex.extract_host(volumes(name), pkg.make_params(iso, **kw))
+                assert_same_mesh(ex.download(), want[name])
+            ex.close()
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
