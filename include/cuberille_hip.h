@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 5
+#define CUBERILLE_ABI_VERSION 6
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -43,7 +43,8 @@ enum {
   CUBERILLE_ERR_HIP = 3,        /* a HIP runtime call failed; text in cuberille_last_error */
   CUBERILLE_ERR_STATE = 4,      /* call order violated (emit before count, ...) */
   CUBERILLE_ERR_HALO = 5,       /* slab does not carry the halo the owned range needs */
-  CUBERILLE_ERR_LIMIT = 6       /* volume exceeds an implementation limit */
+  CUBERILLE_ERR_LIMIT = 6,      /* volume exceeds an implementation limit */
+  CUBERILLE_ERR_SOURCE = 7      /* the chunk source of cuberille_extract_stream reported a failure */
 };
 
 /* InputPixelType of the filter (h:150).  Same numbering as the oracle. */
@@ -143,6 +144,16 @@ int cuberille_set_stream(cuberille_ctx *ctx, void *hip_stream);
  * while the next one is in flight, so the call takes about bytes / link rate (pageable caller memory included). */
 int cuberille_extract_host(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *host_voxels,
                            const cuberille_params *prm, cuberille_result *res);
+/* The same pipeline fed by a PRODUCER instead of a finished host buffer (the reader side of the reference's driver,
+ * Testing/CuberilleTest01.cxx:113-117: itk::ImageFileReader inflates a zlib-compressed MetaImage before the filter
+ * runs).  `source(user, dst, z0, z1)` writes slices [z0, z1) of the volume, x fastest, (z1 - z0) * Nx * Ny pixels, to
+ * `dst` -- pinned staging memory of the library -- and returns 0, or non-zero to give up (CUBERILLE_ERR_SOURCE; the
+ * context stays usable).  It is called on the calling thread, for consecutive z ranges in ascending order, every slice
+ * exactly once.  While it produces one chunk (inflates the next stretch of the file, say) the previous chunk crosses
+ * the link and is thresholded, and the volume never exists as a whole in host memory. */
+typedef int (*cuberille_chunk_source)(void *user, void *dst, int64_t z0, int64_t z1);
+int cuberille_extract_stream(cuberille_ctx *ctx, const cuberille_image_desc *img, cuberille_chunk_source source, void *user,
+                             const cuberille_params *prm, cuberille_result *res);
 /* Same with the volume already resident in HBM (`dev_voxels` is a device pointer). */
 int cuberille_extract_device(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
                              const cuberille_params *prm, const cuberille_slab *slab, cuberille_result *res);

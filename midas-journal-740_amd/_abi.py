@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # CUBERILLE_LIB: load another build of the same ABI (same-box A/B timing of kernel changes)
 LIB_PATH = os.environ.get("CUBERILLE_LIB") or os.path.join(CSRC, "libcuberille_hip.so")
 
-OK, ERR_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_HALO, ERR_LIMIT = range(7)
+OK, ERR_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_HALO, ERR_LIMIT, ERR_SOURCE = range(8)
 
 # every symbol include/cuberille_hip.h declares (tests check the built library exports them all)
 EXPORTS = [
@@ -22,9 +22,9 @@ EXPORTS = [
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
-    "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
+    "cuberille_extract_stream", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ImageDesc(C.Structure):
@@ -58,6 +58,10 @@ class Result(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+# cuberille_chunk_source: int (*)(void *user, void *dst, int64_t z0, int64_t z1)
+CHUNK_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64)
 
 
 class CuberilleError(RuntimeError):
@@ -105,6 +109,7 @@ def lib():
     L.cuberille_destroy.restype = None
     L.cuberille_set_stream.argtypes = [vp, vp]
     L.cuberille_extract_host.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Result)]
+    L.cuberille_extract_stream.argtypes = [vp, C.POINTER(ImageDesc), CHUNK_SOURCE, vp, C.POINTER(Params), C.POINTER(Result)]
     L.cuberille_extract_device.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab),
                                            C.POINTER(Result)]
     L.cuberille_count.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), u64p, u64p]

@@ -651,6 +651,61 @@ int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, co
   return cuberille_emit(c, 0, 0, res);
 }
 
+int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, cuberille_chunk_source source, void *user,
+                             const cuberille_params *prm, cuberille_result *res) {
+  if (c && !source) return fail(c, CUBERILLE_ERR_ARGUMENT, "null chunk source");
+  int rc = validate(c, img, (const void *)source, prm);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t psz = pixel_size(img->pixel_type);
+  const size_t sliceBytes = (size_t)img->dims[0] * img->dims[1] * psz;
+  const size_t nz = (size_t)img->dims[2];
+  HIP_TRY(c, c->voxOwn.reserve(sliceBytes * nz));
+  // chunks of about 32 MiB, whole slices, at least one
+  const size_t slicesPerChunk = sliceBytes >= (32u << 20) ? 1 : (32u << 20) / sliceBytes;
+  const size_t chunkBytes = slicesPerChunk * sliceBytes;
+  const size_t nchunks = (nz + slicesPerChunk - 1) / slicesPerChunk;
+  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  if (c->stageBytes < chunkBytes) {
+    for (int i = 0; i < 2; i++) {
+      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
+      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
+    }
+    c->stageBytes = 0;
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->stage[i], chunkBytes, hipHostMallocDefault));
+    c->stageBytes = chunkBytes;
+  }
+  rc = count_prepare(c, img, c->voxOwn.p, prm, nullptr);
+  if (rc) return rc;
+  hipError_t e = hipSuccess;
+  int gaveUp = 0;
+  for (size_t i = 0; i < nchunks && e == hipSuccess; i++) {
+    const size_t z0 = i * slicesPerChunk, z1 = z0 + slicesPerChunk < nz ? z0 + slicesPerChunk : nz;
+    // the slot is free once chunk i - 2 has crossed the link
+    if (i >= 2) e = hipEventSynchronize(c->chunkIn[i & 1]);
+    if (e != hipSuccess) break;
+    gaveUp = source(user, c->stage[i & 1], (int64_t)z0, (int64_t)z1);
+    if (gaveUp) break;
+    e = hipMemcpyAsync((char *)c->voxOwn.p + z0 * sliceBytes, c->stage[i & 1], (z1 - z0) * sliceBytes, hipMemcpyHostToDevice,
+                       c->copyStream);
+    if (e == hipSuccess) e = hipEventRecord(c->chunkIn[i & 1], c->copyStream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->chunkIn[i & 1], 0);
+    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm.iso, (int)z0, (int)z1, c->tune, c->stream);
+  }
+  if (gaveUp || e != hipSuccess) {
+    // let what is in flight finish before the staging slots are used again
+    (void)hipStreamSynchronize(c->copyStream);
+    (void)hipStreamSynchronize(c->stream);
+    if (gaveUp) return fail(c, CUBERILLE_ERR_SOURCE, "the chunk source gave up with status " + std::to_string(gaveUp));
+    return fail(c, CUBERILLE_ERR_HIP, std::string("streamed upload: ") + hipGetErrorString(e));
+  }
+  uint64_t np = 0, nc = 0;
+  rc = count_finish(c, &np, &nc);
+  if (rc) return rc;
+  return cuberille_emit(c, 0, 0, res);
+}
+
 int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
   if (!c || !out) return CUBERILLE_ERR_ARGUMENT;
   if ((!c->counted && !c->haveMesh) || !c->slabMode || !c->hostOcc)

@@ -21,6 +21,7 @@ PIXEL_CODES = {
     np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
     np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6, np.dtype(np.float64): 7,
 }
+PIXEL_DTYPES = {code: dt for dt, code in PIXEL_CODES.items()}
 
 
 def _torch():
@@ -136,6 +137,43 @@ class Extractor:
             self._ctx, C.byref(desc), C.c_void_p(vox.ctypes.data), C.byref(params), C.byref(res)))
         self.result = res
         return res
+
+    def extract_stream(self, desc, source, params):
+        """The upload pipeline fed by a producer (include/cuberille_hip.h: cuberille_extract_stream).  source(dst, z0, z1)
+        fills the writable numpy array dst ([z1-z0, Ny, Nx], pinned staging memory of the library) with slices [z0, z1)
+        -- e.g. mha.open_stream(path), which inflates a compressed MetaImage stretch by stretch.  An exception raised
+        by source ends the call (CuberilleError ERR_SOURCE, the exception chained as its cause)."""
+        nx, ny, _ = (int(v) for v in desc.dims)
+        dtype = np.dtype(PIXEL_DTYPES[int(desc.pixel_type)])
+        raised = []
+
+        def trampoline(_user, dst, z0, z1):
+            try:
+                n = (z1 - z0) * ny * nx
+                buf = (C.c_char * (n * dtype.itemsize)).from_address(dst)
+                source(np.frombuffer(buf, dtype=dtype).reshape(z1 - z0, ny, nx), int(z0), int(z1))
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- must not unwind through the C frame
+                raised.append(e)
+                return 1
+
+        res = _abi.Result()
+        rc = self._lib.cuberille_extract_stream(self._ctx, C.byref(desc), _abi.CHUNK_SOURCE(trampoline), None,
+                                                C.byref(params), C.byref(res))
+        if rc == _abi.ERR_SOURCE and raised:
+            text = self._lib.cuberille_last_error(self._ctx)
+            raise _abi.CuberilleError(rc, text.decode("utf-8", "replace") if text else "") from raised[0]
+        _abi.check(self._ctx, rc)
+        self.result = res
+        return res
+
+    def extract_mha(self, path, params):
+        """File -> mesh: the MetaImage at `path` is read (and inflated) stretch by stretch straight into the upload
+        pipeline; returns (result, stream info with dims / spacing / origin / direction)."""
+        from .mha import open_stream
+        with open_stream(path) as st:
+            desc = make_desc(st.dtype, st.dims, st.spacing, st.origin, st.direction)
+            return self.extract_stream(desc, st, params), st
 
     def extract_device(self, dev_ptr, desc, params, slab=None):
         res = _abi.Result()

@@ -32,9 +32,8 @@ class Volume:
         return (nx, ny, nz)
 
 
-def read_mha(path):
-    with open(path, "rb") as f:
-        raw = f.read()
+def _parse_header(path, raw):
+    """Header fields of a MetaImage whose first bytes are `raw`; returns (fields, offset of the pixel data)."""
     header = {}
     pos = 0
     while True:
@@ -56,13 +55,29 @@ def read_mha(path):
         raise ValueError("%s: only ElementDataFile = LOCAL is supported" % path)
     if int(header.get("ElementNumberOfChannels", "1")) != 1:
         raise ValueError("%s: only scalar pixels are supported" % path)
-    et = header["ElementType"]
-    if et not in _ELEMENT_TYPES:
-        raise ValueError("%s: unsupported ElementType %s" % (path, et))
-    dtype = np.dtype(_ELEMENT_TYPES[et])
+    if header["ElementType"] not in _ELEMENT_TYPES:
+        raise ValueError("%s: unsupported ElementType %s" % (path, header["ElementType"]))
+    return header, pos
+
+
+def _geometry(header):
+    dtype = np.dtype(_ELEMENT_TYPES[header["ElementType"]])
     msb = header.get("BinaryDataByteOrderMSB", header.get("ElementByteOrderMSB", "False")).lower() == "true"
     dtype = dtype.newbyteorder(">" if msb else "<")
-    nx, ny, nz = (int(t) for t in header["DimSize"].split())
+    dims = tuple(int(t) for t in header["DimSize"].split())
+    spacing = tuple(float(t) for t in header.get("ElementSpacing", "1 1 1").split())
+    origin = tuple(float(t) for t in header.get("Offset", header.get("Position", "0 0 0")).split())
+    tm = header.get("TransformMatrix", header.get("Orientation", "1 0 0 0 1 0 0 0 1"))
+    # MetaIO stores the direction cosines column-wise: row i of TransformMatrix is axis i's direction.
+    direction = np.array([float(t) for t in tm.split()], dtype=np.float64).reshape(3, 3).T
+    return dtype, dims, spacing, origin, direction
+
+
+def read_mha(path):
+    with open(path, "rb") as f:
+        raw = f.read()
+    header, pos = _parse_header(path, raw)
+    dtype, (nx, ny, nz), spacing, origin, direction = _geometry(header)
     payload = raw[pos:]
     if header.get("CompressedData", "False").lower() == "true":
         size = header.get("CompressedDataSize")
@@ -73,12 +88,73 @@ def read_mha(path):
     if len(payload) < need:
         raise ValueError("%s: payload has %d bytes, header needs %d" % (path, len(payload), need))
     vox = np.frombuffer(payload[:need], dtype=dtype).reshape(nz, ny, nx).astype(dtype.newbyteorder("="))
-    spacing = tuple(float(t) for t in header.get("ElementSpacing", "1 1 1").split())
-    origin = tuple(float(t) for t in header.get("Offset", header.get("Position", "0 0 0")).split())
-    tm = header.get("TransformMatrix", header.get("Orientation", "1 0 0 0 1 0 0 0 1"))
-    # MetaIO stores the direction cosines column-wise: row i of TransformMatrix is axis i's direction.
-    direction = np.array([float(t) for t in tm.split()], dtype=np.float64).reshape(3, 3).T
     return Volume(vox, spacing, origin, direction)
+
+
+class MhaStream:
+    """A MetaImage read stretch by stretch: `info` is a Volume-like record without voxels (dims, dtype, spacing,
+    origin, direction); calling the object as source(dst, z0, z1) fills dst with slices [z0, z1), which must be asked
+    for in ascending order without gaps -- the contract of Extractor.extract_stream.  A zlib-compressed payload is
+    inflated as it is read (zlib.decompressobj), so neither the compressed nor the inflated volume is ever held whole."""
+
+    def __init__(self, path, read_bytes=8 << 20):
+        self.path = path
+        self._f = open(path, "rb")
+        head = self._f.read(1 << 16)
+        header, pos = _parse_header(path, head)
+        self.file_dtype, self.dims, self.spacing, self.origin, self.direction = _geometry(header)
+        self.dtype = np.dtype(self.file_dtype.newbyteorder("="))
+        self._f.seek(pos)
+        self._compressed = header.get("CompressedData", "False").lower() == "true"
+        size = header.get("CompressedDataSize")
+        self._left = int(size) if (self._compressed and size is not None) else None     # compressed bytes still in the file
+        self._inflate = zlib.decompressobj() if self._compressed else None
+        self._read_bytes = int(read_bytes)
+        self._z = 0
+
+    def _read(self, n):
+        if self._left is not None:
+            n = min(n, self._left)
+            self._left -= n
+        return self._f.read(n) if n > 0 else b""
+
+    def __call__(self, dst, z0, z1):
+        if z0 != self._z:
+            raise ValueError("%s: slices must be read in order: asked for %d, at %d" % (self.path, z0, self._z))
+        out = dst.reshape(-1).view(np.uint8)
+        need, have = out.size, 0
+        while have < need:
+            if self._compressed:
+                piece = b""
+                if self._inflate.unconsumed_tail:
+                    piece = self._inflate.decompress(self._inflate.unconsumed_tail, need - have)
+                else:
+                    raw = self._read(self._read_bytes)
+                    if not raw:
+                        raise ValueError("%s: compressed payload ends %d bytes short" % (self.path, need - have))
+                    piece = self._inflate.decompress(raw, need - have)
+            else:
+                piece = self._f.read(min(self._read_bytes, need - have))
+                if not piece:
+                    raise ValueError("%s: payload ends %d bytes short" % (self.path, need - have))
+            out[have:have + len(piece)] = np.frombuffer(piece, dtype=np.uint8)
+            have += len(piece)
+        if self.file_dtype.byteorder == ">":
+            dst.byteswap(inplace=True)
+        self._z = z1
+
+    def close(self):
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def open_stream(path):
+    return MhaStream(path)
 
 
 def write_mha(path, vol, compress=True):

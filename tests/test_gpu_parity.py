@@ -1176,3 +1176,62 @@ def test_two_contexts_on_two_threads(pkg, oracle, volumes):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_streamed_ingestion_equals_resident_volume(pkg, oracle, extractor, volumes, tmp_path):
+    """cuberille_extract_stream (decode overlapped with the upload): a compressed
+    MetaImage inflated stretch by stretch into the library's pinned staging memory gives the mesh of the same volume
+    handed over whole -- on every shipped volume, on a five-chunk float volume, on slices larger than a chunk; a
+    source that gives up ends the call with CUBERILLE_ERR_SOURCE and the context goes on working."""
+    import glob
+    import torch
+    kw = dict(triangles=True, project=True, threshold=0.2, step=0.24, relax=0.95, max_steps=40)
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "data", "*.mha"))):
+        vol = pkg.read_mha(path)
+        iso = 128 if "blob" not in path else 200
+        prm = pkg.make_params(iso, **kw)
+        res, info = extractor.extract_mha(path, prm)
+        got = extractor.download()
+        assert info.dims == vol.dims
+        assert_same_mesh(got, oracle.run(vol.voxels, iso, **kw))
+    # several 32 MiB chunks, compressed float payload with geometry
+    n = (600, 256, 256)
+    z, y, x = np.meshgrid(*(np.arange(v, dtype=np.float32) for v in n), indexing="ij")
+    vox = (np.sin(x * 0.11) + np.cos(y * 0.07) * np.sin(z * 0.05) + 0.1 * np.sin(0.9 * x + 0.7 * y + z)).astype(np.float32)
+    del x, y, z
+    vol = pkg.Volume(vox, spacing=(0.5, 1.0, 1.5), origin=(3.0, -1.0, 2.0))
+    path = str(tmp_path / "waves.mha")
+    pkg.write_mha(path, vol, compress=True)
+    prm = pkg.make_params(0.25, triangles=True, project=True, threshold=0.002, step=-1.0, relax=0.95, max_steps=50)
+    extractor.extract_mha(path, prm)
+    streamed = extractor.download()
+    dev = torch.from_numpy(vox).cuda()
+    extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.float32, vol.dims, vol.spacing, vol.origin), prm)
+    whole = extractor.download()
+    assert streamed.points.shape[0] > 500000
+    assert np.array_equal(streamed.cells, whole.cells) and _point_bytes(streamed.points) == _point_bytes(whole.points)
+    # a slice larger than the 32 MiB chunk: one slice per chunk
+    big = np.zeros((3, 2100, 4096), dtype=np.float32)
+    big[1, 500:1500, 1000:3000] = 1.0
+    calls = []
+
+    def source(dst, z0, z1):
+        calls.append((z0, z1))
+        dst[...] = big[z0:z1]
+
+    prm = pkg.make_params(0.5, triangles=False, project=False)
+    extractor.extract_stream(pkg.make_desc(np.float32, (4096, 2100, 3)), source, prm)
+    assert calls == [(0, 1), (1, 2), (2, 3)]
+    assert extractor.download().cells.shape[0] == 2 * 1000 * 2000 + 2 * 1000 + 2 * 2000
+    # the producer gives up half way
+    def failing(dst, z0, z1):
+        if z0 > 0:
+            raise OSError("disk on fire")
+        dst[...] = big[z0:z1]
+
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.extract_stream(pkg.make_desc(np.float32, (4096, 2100, 3)), failing, prm)
+    assert e.value.code == pkg._abi.ERR_SOURCE and isinstance(e.value.__cause__, OSError)
+    vol = volumes("nucleon.mha")
+    extractor.extract_host(vol, pkg.make_params(128, **kw))
+    assert_same_mesh(extractor.download(), oracle.run(vol.voxels, 128, **kw))

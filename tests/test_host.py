@@ -23,7 +23,7 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 5
+    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_the_header(pkg):
@@ -224,3 +224,55 @@ def test_flat_vtk_writer_bytes(pkg, tmp_path):
         lines.append("POLYGONS %d %d" % (n_cells, n_cells * (k + 1)))
         lines += [" ".join([str(k)] + [str(int(i)) for i in c]) for c in cells]
         assert open(path, "rb").read() == ("\n".join(lines) + "\n").encode()
+
+
+def test_streaming_metaimage_reader(pkg, tmp_path):
+    """mha.MhaStream hands out the slices of a MetaImage stretch by stretch (the producer of
+    cuberille_extract_stream): equal to read_mha on every shipped volume for any cut of the z range, on uncompressed
+    and big-endian files too; out-of-order requests and short payloads are errors."""
+    import glob
+    import os
+    from conftest import GOLDEN
+    rng = np.random.default_rng(5)
+    files = sorted(glob.glob(os.path.join(GOLDEN, "data", "*.mha")))
+    assert len(files) == 11
+    for path in files:
+        vol = pkg.read_mha(path)
+        with pkg.open_stream(path) as st:
+            assert st.dims == vol.dims and st.dtype == vol.voxels.dtype
+            assert st.spacing == vol.spacing and st.origin == vol.origin and np.array_equal(st.direction, vol.direction)
+            nz = st.dims[2]
+            cuts = sorted(set([0, nz] + [int(v) for v in rng.integers(1, nz, size=3)]))
+            out = np.empty_like(vol.voxels)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                st(out[a:b], a, b)
+        assert np.array_equal(out, vol.voxels), path
+    vox = (rng.normal(size=(6, 5, 9)) * 1000).astype(np.int16)
+    for compress in (False, True):
+        p = str(tmp_path / ("v%d.mha" % compress))
+        pkg.write_mha(p, pkg.Volume(vox, spacing=(0.5, 1.0, 2.0), origin=(1.0, -2.0, 3.0)), compress=compress)
+        with pkg.open_stream(p, ) as st:
+            out = np.empty_like(vox)
+            st(out[0:4], 0, 4)
+            with pytest.raises(ValueError):
+                st(out[5:6], 5, 6)                       # slice 4 skipped
+            st(out[4:6], 4, 6)
+            assert np.array_equal(out, vox) and st.spacing == (0.5, 1.0, 2.0)
+    # big-endian payload
+    raw = open(str(tmp_path / "v0.mha"), "rb").read()
+    head, data = raw[:raw.index(b"ElementDataFile")], raw[raw.index(b"ElementDataFile"):]
+    body = data[data.index(b"\n") + 1:]
+    swapped = np.frombuffer(body, dtype="<i2").astype(">i2").tobytes()
+    with open(str(tmp_path / "be.mha"), "wb") as f:
+        f.write(head.replace(b"BinaryDataByteOrderMSB = False", b"BinaryDataByteOrderMSB = True") + b"ElementDataFile = LOCAL\n" + swapped)
+    assert np.array_equal(pkg.read_mha(str(tmp_path / "be.mha")).voxels, vox)
+    with pkg.open_stream(str(tmp_path / "be.mha")) as st:
+        out = np.empty_like(vox)
+        st(out, 0, 6)
+        assert np.array_equal(out, vox)
+    # a payload that ends early
+    with open(str(tmp_path / "short.mha"), "wb") as f:
+        f.write(raw[:-40])
+    with pkg.open_stream(str(tmp_path / "short.mha")) as st:
+        with pytest.raises(ValueError):
+            st(np.empty_like(vox), 0, 6)
