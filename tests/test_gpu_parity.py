@@ -1235,3 +1235,35 @@ def test_streamed_ingestion_equals_resident_volume(pkg, oracle, extractor, volum
     vol = volumes("nucleon.mha")
     extractor.extract_host(vol, pkg.make_params(128, **kw))
     assert_same_mesh(extractor.download(), oracle.run(vol.voxels, 128, **kw))
+
+
+def test_plain_c_program_through_the_stream_entry(pkg, oracle, extractor, volumes, tmp_path):
+    """examples/extract_raw.c (C99, built by __graft_entry__.build()): a raw volume read with fread() into
+    cuberille_extract_stream, the reference driver's default parameters, the mesh written by cuberille_mesh_write_vtk --
+    the file equals the one the Python host side writes for the same call, and the mesh is the oracle's."""
+    exe = os.path.join(ROOT, "examples", "build", "extract_raw")
+    if not os.path.exists(exe):
+        pytest.skip("examples/build/extract_raw not built")
+    for name, iso, mode in [("nucleon.mha", 128, "tri"), ("fuel.mha", 15, "quads")]:
+        vol = volumes(name)
+        raw = str(tmp_path / "v.raw")
+        vol.voxels.tofile(raw)
+        out = str(tmp_path / "c.vtk")
+        nx, ny, nz = vol.dims
+        args = [exe, raw, str(nx), str(ny), str(nz), "u8", str(iso), out] + (["quads"] if mode == "quads" else [])
+        r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        kw = dict(triangles=mode == "tri", project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+        want = oracle.run(vol.voxels, iso, **kw)
+        assert "Mesh has %d vertices and %d cells" % (len(want.points), len(want.cells)) in r.stdout
+        run_gpu(pkg, extractor, vol, iso, **kw)
+        py = str(tmp_path / "py.vtk")
+        extractor.write_vtk(py, threads=2)
+        assert open(out, "rb").read() == open(py, "rb").read()
+        pts, cells = _read_vtk_polydata(out)
+        assert np.array_equal(cells, want.cells.astype(np.int64))
+    # a file that ends early: the source gives up, the program reports the library's error
+    open(str(tmp_path / "short.raw"), "wb").write(b"\0" * 1000)
+    r = subprocess.run([exe, str(tmp_path / "short.raw"), "41", "41", "41", "u8", "128", str(tmp_path / "x.vtk")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "chunk source gave up" in r.stderr

@@ -276,3 +276,16 @@ def test_streaming_metaimage_reader(pkg, tmp_path):
     with pkg.open_stream(str(tmp_path / "short.mha")) as st:
         with pytest.raises(ValueError):
             st(np.empty_like(vox), 0, 6)
+
+
+def test_c_abi_from_plain_c(pkg):
+    """include/cuberille_hip.h is C99 and the library links into a plain C program (examples/extract_raw.c, built by
+    __graft_entry__.build()): without a device it says so and exits with 2 -- no fallback on that side either."""
+    import subprocess
+    import __graft_entry__ as graft
+    exe = graft.build_c_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage" in r.stderr
+    if not _has_gpu(pkg):
+        r = subprocess.run([exe, "nothing.raw", "4", "4", "4", "u8", "1", "out.vtk"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "no gfx950 device" in r.stderr, (r.returncode, r.stderr)
