@@ -1267,3 +1267,49 @@ def test_plain_c_program_through_the_stream_entry(pkg, oracle, extractor, volume
     r = subprocess.run([exe, str(tmp_path / "short.raw"), "41", "41", "41", "u8", "128", str(tmp_path / "x.vtk")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and "chunk source gave up" in r.stderr
+
+
+def test_without_the_aliasing_quirk_the_mesh_is_the_geometric_one(pkg, oracle, extractor):
+    """emulate_empty_slice_aliasing = 0 (the one deliberate departure on offer, include/cuberille_hip.h): on sparse
+    volumes with blanked slices -- where the reference re-uses vertices across the gap -- the vertices are exactly the
+    lattice corners whose 2x2x2 block is mixed (the closed form evaluated with numpy), each at corner - spacing/2, and
+    every quad is a unit square of four distinct vertices around a face between an inside and an outside voxel."""
+    rng = np.random.default_rng(99)
+    differs = 0
+    for trial in range(12):
+        shape = (int(rng.integers(5, 12)), int(rng.integers(3, 10)), int(rng.choice([7, 64, 70])))
+        vox = (rng.random(shape) < rng.choice([0.01, 0.05, 0.2])).astype(np.uint8) * 255
+        for z in range(shape[0]):
+            if rng.random() < 0.4:
+                vox[z] = 0
+        mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 128, triangles=0, project=0, q1=False)
+        n_closed, q_closed = oracle.closed_form_counts(vox, 128)
+        assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (n_closed, q_closed)
+        differs += int(len(oracle.run(vox, 128, triangles=False, project=False).points) != n_closed)
+        if n_closed == 0:
+            continue
+        # the vertex set: mixed corners, at index - 0.5
+        ins = vox >= 128
+        p = np.pad(ins, 1, mode="edge")
+        nz, ny, nx = ins.shape
+        blk = np.stack([p[dz:dz + nz + 1, dy:dy + ny + 1, dx:dx + nx + 1] for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)])
+        mixed = blk.any(0) & ~blk.all(0)
+        cz, cy, cx = np.nonzero(mixed)
+        want = set(zip((cx - 0.5).tolist(), (cy - 0.5).tolist(), (cz - 0.5).tolist()))
+        got = [tuple(v) for v in mesh.points.astype(np.float64).tolist()]
+        assert len(set(got)) == len(got) and set(got) == want
+        # every quad: four distinct corners of one unit face, between an inside voxel and an outside one
+        q = mesh.points[mesh.cells.astype(np.int64)].astype(np.float64)      # [n, 4, 3]
+        centre = q.mean(axis=1)
+        assert np.allclose(np.abs(q - centre[:, None, :]).sum(axis=2), 1.0)   # (0.5, 0.5, 0) in some order
+        normal_axis = np.argmin(np.ptp(q, axis=1), axis=1)
+        assert (np.ptp(q, axis=1)[np.arange(len(q)), normal_axis] == 0).all()
+        for c, ax in zip(centre, normal_axis):
+            a, b = c.copy(), c.copy()
+            a[ax] -= 0.5
+            b[ax] += 0.5
+            va, vb = (int(round(v)) for v in a), (int(round(v)) for v in b)
+            xa, ya, za = va
+            xb, yb, zb = vb
+            assert ins[za, ya, xa] != ins[zb, yb, xb]
+    assert differs > 0, "no trial had the quirk change the vertex count"
