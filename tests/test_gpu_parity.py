@@ -1313,3 +1313,38 @@ def test_without_the_aliasing_quirk_the_mesh_is_the_geometric_one(pkg, oracle, e
             xb, yb, zb = vb
             assert ins[za, ya, xa] != ins[zb, yb, xb]
     assert differs > 0, "no trial had the quirk change the vertex count"
+
+
+def test_slabs_without_the_aliasing_quirk(pkg, extractor):
+    """emulate_empty_slice_aliasing = 0 in slab mode: no slice of another rank is ever needed beyond the halo, and the
+    slabs of a sparse volume with empty slices AT the cuts concatenate to the one-shot mesh of the same setting."""
+    import torch
+    rng = np.random.default_rng(123)
+    vox = (rng.random((40, 9, 70)) < 0.05).astype(np.uint8) * 255
+    vox[9:12] = 0
+    vox[19:21] = 0
+    vox[30] = 0
+    vol = pkg.Volume(vox)
+    nx, ny, nz = vol.dims
+    for tri in (False, True):
+        kw = dict(triangles=tri, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=20, q1=False)
+        prm = pkg.make_params(128, **kw)
+        extractor.extract_host(vol, prm)
+        whole = extractor.download()
+        below, above = pkg.required_halo(pkg.make_desc(vox.dtype, vol.dims), prm)
+        pts, cells, poff = [], [], 0
+        for a, b in zip([0, 10, 20, 31], [10, 20, 31, nz]):
+            lo, hi = max(a - below, 0), min(b + above, nz)
+            slab_vox = torch.from_numpy(np.ascontiguousarray(vox[lo:hi])).cuda()
+            n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vox.dtype, (nx, ny, hi - lo)), prm,
+                                       pkg._abi.Slab(nz, lo, a, b, 0, 0))
+            soft, _, _ = extractor.slab_info()
+            assert not soft                                   # nothing to resolve with the quirk off
+            extractor.emit(poff, 0)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+        got = pkg.Mesh(np.concatenate(pts), np.concatenate(cells))
+        assert np.array_equal(got.cells, whole.cells)
+        assert _point_bytes(got.points) == _point_bytes(whole.points)
