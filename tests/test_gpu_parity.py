@@ -1348,3 +1348,32 @@ def test_slabs_without_the_aliasing_quirk(pkg, extractor):
         got = pkg.Mesh(np.concatenate(pts), np.concatenate(cells))
         assert np.array_equal(got.cells, whole.cells)
         assert _point_bytes(got.points) == _point_bytes(whole.points)
+
+
+def test_slabs_under_a_tilted_direction_matrix(pkg, oracle, extractor):
+    """The halo follows the z row of PhysicalPointToIndex: with the image tilted about its x axis (physical steps mix
+    into index y and z) and anisotropic spacing, slabs carrying exactly cuberille_required_halo reproduce the oracle's
+    whole-volume mesh, coordinates bit for bit."""
+    import torch
+    vox = pkg.volumes.sphere_sdf(56)
+    th = 0.4
+    direction = np.array([[1.0, 0.0, 0.0], [0.0, np.cos(th), -np.sin(th)], [0.0, np.sin(th), np.cos(th)]])
+    geo = dict(spacing=(1.0, 0.8, 0.6), origin=(2.0, -3.0, 0.5), direction=direction)
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.3, relax=0.95, max_steps=40)
+    prm = pkg.make_params(0.0, **kw)
+    ref = oracle.run(vox, 0.0, **geo, **kw)
+    nz, ny, nx = vox.shape
+    below, above = pkg.required_halo(pkg.make_desc(np.float32, (nx, ny, nz), **geo), prm)
+    assert below > 8                      # more than the unit-spacing default
+    dev = torch.from_numpy(vox).cuda()
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 17), (17, 30), (30, 56)]:
+        lo, hi = max(a - below, 0), min(b + above, nz)
+        n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (nx, ny, hi - lo), **geo), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
