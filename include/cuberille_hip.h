@@ -65,7 +65,8 @@ typedef struct {
 
 /* The filter's parameters: h:180-228, constructor defaults txx:33-40. */
 typedef struct {
-  double iso_value;              /* m_IsoSurfaceValue; converted to the pixel type (txx:140) */
+  double iso_value;              /* m_IsoSurfaceValue, an InputPixelType in the reference (h:180-181): converted to the pixel
+                                    type like a C cast; outside an integer type's range (or NaN for one): ERR_ARGUMENT */
   int32_t generate_triangles;    /* m_GenerateTriangleFaces (default 1) */
   int32_t project_vertices;      /* m_ProjectVerticesToIsoSurface (default 1) */
   double distance_threshold;     /* m_ProjectVertexSurfaceDistanceThreshold (0.5) */

@@ -141,6 +141,20 @@ int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox,
   }
   if (prm->projection_variant < CUBERILLE_PROJECT_DEFAULT || prm->projection_variant > CUBERILLE_PROJECT_LINESEARCH)
     return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown projection variant");
+  // the iso value is an InputPixelType in the reference (h:180-181): for the integer pixel types it must convert
+  // without leaving the type's range (a fraction is cut off like a C cast does)
+  double lo = 0.0, hi = 0.0;
+  switch (img->pixel_type) {
+    case CUBERILLE_PIX_U8: hi = 255.0; break;
+    case CUBERILLE_PIX_I8: lo = -128.0; hi = 127.0; break;
+    case CUBERILLE_PIX_U16: hi = 65535.0; break;
+    case CUBERILLE_PIX_I16: lo = -32768.0; hi = 32767.0; break;
+    case CUBERILLE_PIX_U32: hi = 4294967295.0; break;
+    case CUBERILLE_PIX_I32: lo = -2147483648.0; hi = 2147483647.0; break;
+    default: lo = hi = 0.0; break;
+  }
+  if (hi != lo && !(prm->iso_value > lo - 1.0 && prm->iso_value < hi + 1.0))
+    return fail(c, CUBERILLE_ERR_ARGUMENT, "iso value is not representable in the pixel type");
   return CUBERILLE_OK;
 }
 

@@ -1075,6 +1075,13 @@ def test_unknown_projection_variant_is_refused(pkg, extractor, volumes):
     with pytest.raises(pkg._abi.CuberilleError) as e:
         extractor.extract_host(vol, pkg.make_params(200, variant=3))
     assert e.value.code == pkg._abi.ERR_ARGUMENT
+    # an iso value outside the (integer) pixel type: the reference cannot even express it (h:180-181)
+    for iso in (256.0, -1.0, float("nan"), 1e30):
+        with pytest.raises(pkg._abi.CuberilleError) as e:
+            extractor.extract_host(vol, pkg.make_params(iso))
+        assert e.value.code == pkg._abi.ERR_ARGUMENT and "iso value" in str(e.value)
+    for iso in (255.9, -0.5, 0.0):                            # cut off like a C cast: 255, 0, 0
+        extractor.extract_host(vol, pkg.make_params(iso))
     extractor.extract_host(vol, pkg.make_params(200))        # the context stays usable
 
 
