@@ -1384,3 +1384,21 @@ def test_slabs_under_a_tilted_direction_matrix(pkg, oracle, extractor):
         cells.append(m.cells)
         poff += n_p
     assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def test_extreme_aspect_ratios(pkg, oracle, extractor):
+    """Needles, sheets and single rows: one-voxel axes in every position, row lengths around the word and the staging
+    granules, thousands of slices of a few voxels."""
+    rng = np.random.default_rng(1)
+    shapes = [(5000, 1, 1), (1, 3000, 1), (1, 1, 3000), (20000, 2, 2), (300, 1, 70), (1, 70, 300), (2, 3, 4097), (3, 2, 8191),
+              (7, 5, 1025), (2, 1, 1), (1, 2, 64), (9, 1, 128), (4000, 3, 65)]
+    for shape in shapes:
+        for dens in (0.1, 0.5):
+            vox = (rng.random(shape) < dens).astype(np.uint8) * 200
+            for tri, proj in ((0, 0), (1, 1)):
+                kw = dict(triangles=tri, project=proj, threshold=0.2, step=0.25, relax=0.95, max_steps=10)
+                mesh = run_gpu(pkg, extractor, pkg.Volume(vox), 100, **kw)
+                try:
+                    assert_same_mesh(mesh, oracle.run(vox, 100, **kw))
+                except AssertionError as e:
+                    raise AssertionError("shape %s density %s %s: %s" % (shape, dens, kw, e))
