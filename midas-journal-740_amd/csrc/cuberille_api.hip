@@ -786,17 +786,100 @@ int cuberille_mesh_device(const cuberille_ctx *c, const float **d_points, const 
   return CUBERILLE_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Device -> pageable host memory: 32 MiB chunks land in the pinned staging slots on the copy stream while a few host
+// threads move the previous chunk to its destination.  What this buys is the FIRST touch of a freshly allocated
+// destination (the usual case: one result array per extraction), which the page faults bound: 668 MB in 48 ms against
+// 65 ms for one plain hipMemcpy on the same box; into memory that has been touched before both run at the link's
+// 52-55 GB/s (12.9 against 12.2 ms).  Small copies take the plain way.
+int download_pipelined(cuberille_ctx *c, void *dst, const void *src, size_t bytes) {
+  const size_t kChunk = 32u << 20;
+  if (bytes < 4 * kChunk) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CUBERILLE_OK;
+  }
+  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  if (c->stageBytes < kChunk) {
+    for (int i = 0; i < 2; i++) {
+      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
+      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
+    }
+    c->stageBytes = 0;
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->stage[i], kChunk, hipHostMallocDefault));
+    c->stageBytes = kChunk;
+  }
+  // the mesh was written on the context's stream
+  HIP_TRY(c, hipEventRecord(c->stageFree[0], c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->stageFree[0], 0));
+  const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nT = (int)(hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1));
+  std::vector<std::atomic<int>> landed(nchunks), moved(nchunks);
+  for (size_t i = 0; i < nchunks; i++) { landed[i].store(0); moved[i].store(0); }
+  std::atomic<bool> abort{false};
+  std::vector<std::thread> workers;
+  for (int t = 0; t < nT; t++) {
+    workers.emplace_back([&, t] {
+      for (size_t i = 0; i < nchunks; i++) {
+        while (!landed[i].load(std::memory_order_acquire)) {
+          if (abort.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
+        const size_t off = i * kChunk, cb = bytes - off < kChunk ? bytes - off : kChunk;
+        const size_t a = cb * t / nT & ~(size_t)63, b = (t == nT - 1) ? cb : (cb * (t + 1) / nT & ~(size_t)63);
+        std::memcpy((char *)dst + off + a, (const char *)c->stage[i & 1] + a, b - a);
+        moved[i].fetch_add(1, std::memory_order_release);
+      }
+    });
+  }
+  auto issue = [&](size_t i) -> hipError_t {
+    const size_t off = i * kChunk, cb = bytes - off < kChunk ? bytes - off : kChunk;
+    hipError_t e = hipMemcpyAsync(c->stage[i & 1], (const char *)src + off, cb, hipMemcpyDeviceToHost, c->copyStream);
+    if (e == hipSuccess) e = hipEventRecord(c->chunkIn[i & 1], c->copyStream);
+    return e;
+  };
+  hipError_t e = issue(0);
+  for (size_t i = 0; i < nchunks && e == hipSuccess; i++) {
+    if (i + 1 < nchunks) {
+      // slot (i + 1) & 1 held chunk i - 1: the host threads must be done with it
+      if (i >= 1) while (moved[i - 1].load(std::memory_order_acquire) < nT) std::this_thread::yield();
+      e = issue(i + 1);
+      if (e != hipSuccess) break;
+    }
+    e = hipEventSynchronize(c->chunkIn[i & 1]);
+    if (e == hipSuccess) landed[i].store(1, std::memory_order_release);
+  }
+  if (e != hipSuccess) abort.store(true);
+  for (auto &w : workers) w.join();
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(c->copyStream);
+    return fail(c, CUBERILLE_ERR_HIP, std::string("mesh download: ") + hipGetErrorString(e));
+  }
+  return CUBERILLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int cuberille_mesh_download(cuberille_ctx *c, float *points, uint64_t *cells) {
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");
   HIP_TRY(c, hipSetDevice(c->device));
   const cuberille_result &r = c->res;
-  if (points && r.n_points)
-    HIP_TRY(c, hipMemcpyAsync(points, (const float *)c->points.p + 3 * c->tot.V0, r.n_points * 3 * sizeof(float),
-                              hipMemcpyDeviceToHost, c->stream));
-  if (cells && r.n_cells)
-    HIP_TRY(c, hipMemcpyAsync(cells, c->cells.p, r.n_cells * r.verts_per_cell * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, c->stream));
+  if (points && r.n_points) {
+    const int rc = download_pipelined(c, points, (const float *)c->points.p + 3 * c->tot.V0, r.n_points * 3 * sizeof(float));
+    if (rc) return rc;
+  }
+  if (cells && r.n_cells) {
+    const int rc = download_pipelined(c, cells, c->cells.p, r.n_cells * r.verts_per_cell * sizeof(uint64_t));
+    if (rc) return rc;
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CUBERILLE_OK;
 }

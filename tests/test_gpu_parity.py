@@ -564,6 +564,13 @@ def test_noise_u8_config5_properties(pkg, extractor):
     extractor.extract_device(vol.data_ptr(), desc, prm)
     whole = extractor.download()
     assert (whole.GetNumberOfPoints(), whole.GetNumberOfCells()) == (want_pts, 2 * want_quads)
+    # the download of a mesh this size runs chunked through the pinned staging slots: same bytes as the device buffers
+    from midas_journal_740_amd.distributed import mesh_tensors
+    dev_pts, dev_cells = mesh_tensors(extractor, vol.device)
+    assert whole.cells.nbytes > (128 << 20)
+    assert np.array_equal(dev_cells.cpu().numpy().view(np.uint64), whole.cells)
+    assert np.array_equal(dev_pts.cpu().numpy().view(np.uint32), whole.points.view(np.uint32))
+    del dev_pts, dev_cells
     words = extractor.debug_bits((n, n, n))
     bits = torch.from_numpy(words.view(np.int64)).cuda()
     shifts = torch.arange(64, device="cuda", dtype=torch.int64)
