@@ -571,6 +571,8 @@ def test_noise_u8_config5_properties(pkg, extractor):
     assert np.array_equal(dev_cells.cpu().numpy().view(np.uint64), whole.cells)
     assert np.array_equal(dev_pts.cpu().numpy().view(np.uint32), whole.points.view(np.uint32))
     del dev_pts, dev_cells
+    again = extractor.download(out=whole)                     # the same arrays written again
+    assert again.points is whole.points and again.cells is whole.cells
     words = extractor.debug_bits((n, n, n))
     bits = torch.from_numpy(words.view(np.int64)).cuda()
     shifts = torch.arange(64, device="cuda", dtype=torch.int64)
