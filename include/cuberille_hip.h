@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 6
+#define CUBERILLE_ABI_VERSION 7
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -115,14 +115,17 @@ typedef struct {
   uint64_t n_cells;         /* cells this call/rank owns (quads, or 2 triangles per quad) */
   int32_t verts_per_cell;   /* 4 or 3 */
   int32_t reserved;
-  /* device time of each stage in milliseconds (HIP events on the context's stream) */
+  /* Device time in milliseconds (HIP events on the context's stream).  ms_pass and ms_total are always measured; the five
+   * per-stage figures only with cuberille_debug_set_option(ctx, "stage_timing", 1) and are 0 otherwise: every event
+   * between two kernels costs the stream about 8 us, 1 % of a 1024^3 extraction for the three it takes. */
   float ms_classify;        /* threshold + bit-pack sweep over the volume */
   float ms_count;           /* per-word face / created-corner counts and all prefix sums (one kernel) */
   float ms_scan;            /* 0: the scans run inside the count kernel since ABI 4 (field kept for layout) */
   float ms_emit_points;     /* vertex scatter: AddVertex without the projection (txx:256-276) */
   float ms_project;         /* vertex projection (txx:439-474) */
   float ms_emit_cells;      /* quad / triangle scatter incl. the diagonal split (txx:278-332) */
-  float ms_total;           /* first classify launch .. last kernel done */
+  float ms_total;           /* ms_pass + the emit phase (points, projection, cells); not the host round trip between them */
+  float ms_pass;            /* classify + count + scan: the pass over the volume (sits in what was padding before ABI 7) */
   uint64_t proj_iterations; /* total iterations of the projection loop */
 } cuberille_result;
 

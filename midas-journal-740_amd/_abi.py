@@ -24,7 +24,7 @@ EXPORTS = [
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_extract_stream", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ImageDesc(C.Structure):
@@ -54,7 +54,7 @@ class Result(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("verts_per_cell", C.c_int32),
                 ("reserved", C.c_int32), ("ms_classify", C.c_float), ("ms_count", C.c_float),
                 ("ms_scan", C.c_float), ("ms_emit_points", C.c_float), ("ms_project", C.c_float),
-                ("ms_emit_cells", C.c_float), ("ms_total", C.c_float), ("proj_iterations", C.c_uint64)]
+                ("ms_emit_cells", C.c_float), ("ms_total", C.c_float), ("ms_pass", C.c_float), ("proj_iterations", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}

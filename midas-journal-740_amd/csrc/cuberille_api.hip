@@ -72,6 +72,7 @@ struct cuberille_ctx {
   const float *extPts = nullptr;
   // state of the last count
   bool counted = false, haveMesh = false, slabMesh = false;
+  bool stagesTimed = false;              // the per-stage events of the running count/emit pair are being recorded
   Grid g{};
   Geo geo{};
   Params prm{};
@@ -361,6 +362,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(w.sliceOcc, 0, (size_t)g.nzb * sizeof(u32), s));
   HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals), s));
+  c->stagesTimed = c->tune.stage_timing != 0;
   HIP_TRY(c, hipEventRecord(c->ev[0], s));
   c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
   c->nwords = nwords; c->nseg = nseg;
@@ -372,7 +374,7 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
   hipStream_t s = c->stream;
   const Grid &g = c->g;
   const Workspace &w = c->w;
-  HIP_TRY(c, hipEventRecord(c->ev[1], s));
+  if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   HIP_TRY(c, launch_occupancy(w, g, s));
   HIP_TRY(c, launch_count(w, g, c->nwords, c->prm.q1, s));
   HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -529,9 +531,9 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
   HIP_TRY(c, launch_heads(w, c->g, c->tot.totV, c->tot.totQ, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, c->tot.nVertexWords, c->tune, s));
-  HIP_TRY(c, hipEventRecord(c->ev[5], s));
+  if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, s));
-  HIP_TRY(c, hipEventRecord(c->ev[6], s));
+  if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, c->extIds, s));
@@ -540,16 +542,18 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   HIP_TRY(c, hipStreamSynchronize(s));
   c->tot.iters = c->hostTotals->iters;
   cuberille_result &r = c->res;
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
   r.ms_scan = 0.0f;                          // the scans run inside the count kernel (its last block)
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->ev[6], c->ev[7]));
-  float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[2]));
+  if (c->stagesTimed) {                      // (the switch as it was when the count ran)
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->ev[6], c->ev[7]));
+  }
+  float b = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
   HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
-  r.ms_total = a + b;                        // device time; excludes the host gap between count and emit
+  r.ms_total = r.ms_pass + b;                // device time; excludes the host gap between count and emit
   r.proj_iterations = c->tot.iters;
   c->haveMesh = true;
   c->counted = false;                        // the workspace now belongs to this mesh
@@ -738,7 +742,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal)
+  OPT(points_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing)
 #undef OPT
   return false;
 }

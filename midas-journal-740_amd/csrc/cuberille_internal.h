@@ -86,6 +86,7 @@ struct Tuning {
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
+  int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
 
 struct Params {

@@ -40,6 +40,7 @@ def main():
     keys = ["ms_classify", "ms_count", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
     for combo in itertools.product(*values) if names else [()]:
         ex.debug_option("defaults", 0)
+        ex.debug_option("stage_timing", 1)
         for k, v in zip(names, combo):
             ex.debug_option(k, v)
         rows = []
