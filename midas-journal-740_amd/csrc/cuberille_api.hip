@@ -53,7 +53,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, totals, points, cells, cmap, headV, headQ, vqueue;
+  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue;
   Totals *hostTotals = nullptr;          // pinned
   uint32_t *hostOcc = nullptr;           // pinned mirror of the per-slice occupancy of the last slab count
   size_t hostOccCap = 0;
@@ -193,7 +193,6 @@ int cuberille_create(cuberille_ctx **out, int device_id) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void **)&c->hostTotals, sizeof(Totals), hipHostMallocDefault);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
-  if (e == hipSuccess) e = c->totals.reserve(sizeof(Totals));
   if (e != hipSuccess) {
     g_create_error = std::string("cuberille_create: ") + hipGetErrorString(e);
     cuberille_destroy(c);
@@ -210,7 +209,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (c->own) (void)hipStreamSynchronize(c->own);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
-                    &c->totals, &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
+                    &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   if (c->hostOcc) (void)hipHostFree(c->hostOcc);
@@ -338,7 +337,9 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->slabMode = !whole;
   c->extIds = nullptr;
   c->extPts = nullptr;
-  HIP_TRY(c, c->occ.reserve((size_t)g.nzb * sizeof(u32)));
+  // the totals and the per-slice occupancy share one allocation: one memset zeroes both
+  static_assert(sizeof(Totals) % 16 == 0, "the occupancy words follow the totals");
+  HIP_TRY(c, c->occ.reserve(sizeof(Totals) + (size_t)g.nzb * sizeof(u32)));
   HIP_TRY(c, c->prefix.reserve(nwords * sizeof(u32)));
   HIP_TRY(c, c->segPre.reserve(nseg * sizeof(u64)));
   HIP_TRY(c, c->blockTot.reserve(nblk * sizeof(u64)));
@@ -354,14 +355,13 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
     w.vqueue = (u32 *)c->vqueue.p;
   else (void)hipGetLastError();
   w.vox = dev_voxels;
-  w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)c->occ.p;
+  w.bits = (u64 *)c->bits.p; w.sliceOcc = (u32 *)((char *)c->occ.p + sizeof(Totals));
   w.prefix = (u32 *)c->prefix.p;
   w.segPre = (u64 *)c->segPre.p; w.blockTot = (u64 *)c->blockTot.p; w.blockBase = (u64 *)c->blockBase.p;
-  w.totals = (Totals *)c->totals.p;
+  w.totals = (Totals *)c->occ.p;
 
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipMemsetAsync(w.sliceOcc, 0, (size_t)g.nzb * sizeof(u32), s));
-  HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals), s));
+  HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals) + (size_t)g.nzb * sizeof(u32), s));
   c->stagesTimed = c->tune.stage_timing != 0;
   HIP_TRY(c, hipEventRecord(c->ev[0], s));
   c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
@@ -919,7 +919,7 @@ int cuberille_slice_occupancy(cuberille_ctx *c, uint32_t *occupied, size_t n_sli
   if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no classified volume on this context");
   if (n_slices > (size_t)c->g.nzb) return fail(c, CUBERILLE_ERR_ARGUMENT, "more slices requested than the buffer holds");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(occupied, c->occ.p, n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(occupied, c->w.sliceOcc, n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CUBERILLE_OK;
 }
