@@ -1411,3 +1411,24 @@ def test_extreme_aspect_ratios(pkg, oracle, extractor):
                     assert_same_mesh(mesh, oracle.run(vox, 100, **kw))
                 except AssertionError as e:
                     raise AssertionError("shape %s density %s %s: %s" % (shape, dens, kw, e))
+
+
+def test_stage_timing_is_on_request(pkg, volumes):
+    """cuberille_result: ms_pass and ms_total are measured by every extraction; the five per-stage figures only with the
+    context's stage_timing switch (each event between two kernels costs the stream microseconds), 0 otherwise."""
+    vol = volumes("hydrogenAtom.mha")
+    prm = pkg.make_params(15, triangles=True, project=True)
+    ex = pkg.Extractor(0)
+    stages = ("ms_classify", "ms_count", "ms_emit_points", "ms_project", "ms_emit_cells")
+    r = ex.extract_host(vol, prm)
+    assert r.ms_pass > 0 and r.ms_total > r.ms_pass
+    assert all(getattr(r, k) == 0.0 for k in stages)
+    ex.debug_option("stage_timing", 1)
+    r = ex.extract_host(vol, prm)
+    assert all(getattr(r, k) > 0.0 for k in stages)
+    assert abs(r.ms_classify + r.ms_count - r.ms_pass) < 0.02 * r.ms_pass + 0.005
+    assert abs(r.ms_pass + r.ms_emit_points + r.ms_project + r.ms_emit_cells - r.ms_total) < 0.02 * r.ms_total + 0.01
+    ex.debug_option("defaults", 0)
+    r = ex.extract_host(vol, prm)
+    assert all(getattr(r, k) == 0.0 for k in stages) and r.ms_pass > 0
+    ex.close()
