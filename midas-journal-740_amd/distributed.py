@@ -220,6 +220,7 @@ class ShardedExtractor:
         self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
         self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None, None)
         self._halo_event = None
+        self.force_event_path = False             # tests: the non-blocking exchange + event hand-off without RCCL
         self._vox_event = None
         self.check_aliasing = check_aliasing
         self.cross_slab_aliasing = cross_slab_aliasing
@@ -228,7 +229,6 @@ class ShardedExtractor:
     def extract(self, buf, params):
         """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid (written on torch's current stream).
         Runs halo exchange, count, the count all-gather and emit; leaves this rank's mesh part on its device."""
-        import os
         import torch
         import torch.distributed as dist
         from . import _abi
@@ -239,8 +239,8 @@ class ShardedExtractor:
             if need > self.halo:
                 raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "
                                  "with a halo of %d (pass params= or halo= to its constructor)" % (need, self.halo))
-            # (CUBERILLE_FORCE_EVENT_PATH: take this branch under gloo too -- test hook for one-GPU boxes)
-            if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or os.environ.get("CUBERILLE_FORCE_EVENT_PATH")):
+            # (self.force_event_path: take this branch under gloo too -- what the tests on one-GPU boxes set)
+            if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or self.force_event_path):
                 # RCCL: do not wait on the host.  The library runs on its own stream: one event tells it when the
                 # owned slices (produced on torch's current stream) are valid, a second one, recorded behind the
                 # transfers, when the halo slices are in; it thresholds the owned slices meanwhile.

@@ -281,8 +281,6 @@ def test_reference_driver_unchanged(pkg, extractor, oracle, volumes, ctest_cases
 
 def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0.24):
     import os
-    if event_path:
-        os.environ["CUBERILLE_FORCE_EVENT_PATH"] = "1"
     import sys
     import torch
     import torch.distributed as dist
@@ -300,6 +298,7 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
         ex = pkg.Extractor(0)
         prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=0.95, max_steps=100)
         sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm)
+        sh.force_event_path = bool(event_path)
         assert sh.halo == (8 if step == 0.24 else 13)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()   # owned slices only
