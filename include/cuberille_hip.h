@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 7
+#define CUBERILLE_ABI_VERSION 8
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -169,6 +169,10 @@ int cuberille_count(cuberille_ctx *ctx, const cuberille_image_desc *img, const v
                     uint64_t *n_points, uint64_t *n_cells);
 int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, uint64_t cell_id_offset,
                    cuberille_result *res);
+/* Optional, between the two: starts the part of the emit that needs no id offset -- head tables, vertex scatter,
+ * projection -- and returns at once, so that the GPU works while the caller gathers the other ranks' counts;
+ * cuberille_emit then only adds the cells.  A cuberille_recount after it voids what it started. */
+int cuberille_emit_points(cuberille_ctx *ctx);
 /* Slices a slab buffer must hold below own_z0 and above own_z1 (where the volume does not end) for these
  * parameters: 2 / 1 for the topology, and as far as the projection walk can carry a vertex -- step *
  * sum(relaxation^k, k <= max_steps+1) over the z spacing -- plus the interpolation cell and the gradient ring.

@@ -22,9 +22,9 @@ EXPORTS = [
     "cuberille_count", "cuberille_emit", "cuberille_mesh_device", "cuberille_mesh_download",
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
-    "cuberille_extract_stream", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
+    "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
 ]
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ImageDesc(C.Structure):
@@ -114,6 +114,7 @@ def lib():
                                            C.POINTER(Result)]
     L.cuberille_count.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), u64p, u64p]
     L.cuberille_emit.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Result)]
+    L.cuberille_emit_points.argtypes = [vp]
     L.cuberille_mesh_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cuberille_mesh_download.argtypes = [vp, vp, vp]
     L.cuberille_debug_bits.argtypes = [vp, vp, C.c_size_t]

@@ -72,6 +72,7 @@ struct cuberille_ctx {
   const float *extPts = nullptr;
   // state of the last count
   bool counted = false, haveMesh = false, slabMesh = false;
+  bool pointsEmitted = false;            // the offset-free part of the emit has been launched for the current count
   bool stagesTimed = false;              // the per-stage events of the running count/emit pair are being recorded
   Grid g{};
   Geo geo{};
@@ -280,6 +281,7 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
 int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
                   const cuberille_slab *slab) {
   c->counted = false;
+  c->pointsEmitted = false;
   c->haveMesh = false;
   c->aliasBelowBuffer = false;
   c->aliasMustResolve = false;
@@ -456,6 +458,7 @@ int cuberille_recount(cuberille_ctx *c, const void *dev_source_bits, uint64_t *n
                             hipMemcpyDeviceToDevice, s));
   c->g.extAlias = 1;
   c->counted = false;
+  c->pointsEmitted = false;                  // the counts change: whatever cuberille_emit_points started is void
   HIP_TRY(c, hipMemsetAsync(c->w.totals, 0, sizeof(Totals), s));
   return count_finish(c, n_points, n_cells);
 }
@@ -490,23 +493,20 @@ int cuberille_set_alias_plane(cuberille_ctx *c, const uint64_t *dev_ids, const f
   return CUBERILLE_OK;
 }
 
-int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
-  if (!c) return CUBERILLE_ERR_ARGUMENT;
-  if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit called before a successful cuberille_count");
-  if (c->g.extAlias && (!c->extIds || !c->extPts))
-    return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
-  if (c->aliasMustResolve)
-    return fail(c, CUBERILLE_ERR_HALO,
-                "an empty slice makes the reference re-use vertices created below this slab's counted range: hand the "
-                "source slice over with cuberille_recount (DESIGN.md Q1)");
-  (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
-  c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
-  c->pointOffset = point_id_offset;
+}  // extern "C"
+
+namespace {
+
+// The part of the emit that needs no id offsets: buffers, head tables, vertex scatter, projection.  Runs once per count
+// (cuberille_emit_points may have started it already, while the caller was gathering the counts of the other ranks).
+int emit_points_phase(cuberille_ctx *c) {
+  if (c->pointsEmitted) return CUBERILLE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 nV = c->tot.totV;                 // ghost + owned
   const u64 nGhost = c->tot.V0;
   const u64 nQ = c->tot.totQ - c->tot.Q0;
-  const size_t planeCorners = c->g.extAlias ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
+  // room behind this rank's points for the positions of a plane of the rank below's vertices (quirk Q1 across slabs)
+  const size_t planeCorners = (c->slabMode || c->g.extAlias) ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;
   HIP_TRY(c, c->points.reserve((size_t)(nV + planeCorners ? nV + planeCorners : 1) * 3 * sizeof(float)));
   HIP_TRY(c, c->cells.reserve((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
   Workspace &w = c->w;
@@ -534,6 +534,46 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
   if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
+  c->pointsEmitted = true;
+  return CUBERILLE_OK;
+}
+
+int emit_preconditions(cuberille_ctx *c, const char *who) {
+  if (!c->counted) return fail(c, CUBERILLE_ERR_STATE, std::string(who) + " called before a successful cuberille_count");
+  if (c->aliasMustResolve)
+    return fail(c, CUBERILLE_ERR_HALO,
+                "an empty slice makes the reference re-use vertices created below this slab's counted range: hand the "
+                "source slice over with cuberille_recount (DESIGN.md Q1)");
+  return CUBERILLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cuberille_emit_points(cuberille_ctx *c) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  const int rc = emit_preconditions(c, "cuberille_emit_points");
+  if (rc) return rc;
+  return emit_points_phase(c);
+}
+
+int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  int rc = emit_preconditions(c, "cuberille_emit");
+  if (rc) return rc;
+  if (c->g.extAlias && (!c->extIds || !c->extPts))
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
+  (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
+  c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
+  c->pointOffset = point_id_offset;
+  rc = emit_points_phase(c);
+  if (rc) return rc;
+  const u64 nV = c->tot.totV;
+  const u64 nQ = c->tot.totQ - c->tot.Q0;
+  const size_t planeCorners = c->g.extAlias ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
+  Workspace &w = c->w;
+  hipStream_t s = c->stream;
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, c->extIds, s));

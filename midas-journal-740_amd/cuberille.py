@@ -190,6 +190,10 @@ class Extractor:
             C.byref(slab) if slab is not None else None, C.byref(npnt), C.byref(ncell)))
         return int(npnt.value), int(ncell.value)
 
+    def emit_points(self):
+        """Start the offset-free part of the emit (vertex scatter, projection) right after count(); returns at once."""
+        _abi.check(self._ctx, self._lib.cuberille_emit_points(self._ctx))
+
     def emit(self, point_id_offset=0, cell_id_offset=0):
         res = _abi.Result()
         _abi.check(self._ctx, self._lib.cuberille_emit(self._ctx, int(point_id_offset), int(cell_id_offset),

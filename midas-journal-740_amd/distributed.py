@@ -275,6 +275,10 @@ class ShardedExtractor:
             n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab)
             if self.check_aliasing and params.emulate_empty_slice_aliasing:
                 soft, _, top = self.ex.slab_info()
+            if not soft:
+                # nothing another rank says can change this rank's counts: the vertices are scattered and projected
+                # while the counts are gathered, only the cells wait for the id offsets
+                self.ex.emit_points()
         except _abi.CuberilleError as e:
             failed = e
         del keep

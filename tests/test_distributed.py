@@ -192,7 +192,11 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         def emit(poff, coff):
             calls["offsets"] = (poff, coff)
             return types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
-        fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, result=None)
+        def emit_points():
+            # only a rank whose counts nothing can change may start early
+            calls["early"] = True
+            assert not slab_info()[0]
+        fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, emit_points=emit_points, result=None)
         prm = pkg.make_params(0.5)
         # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused)
         sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm, cross_slab_aliasing=False)

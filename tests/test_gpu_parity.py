@@ -1431,3 +1431,34 @@ def test_stage_timing_is_on_request(pkg, volumes):
     r = ex.extract_host(vol, prm)
     assert all(getattr(r, k) == 0.0 for k in stages) and r.ms_pass > 0
     ex.close()
+
+
+def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
+    """cuberille_emit_points between count and emit (the multi-GPU driver calls it before the count all-gather): the
+    vertices are scattered and projected without the id offsets, cuberille_emit adds the cells -- same mesh as without
+    it; calling it with nothing counted is a state error; a recount after it starts over."""
+    import torch
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        pkg.Extractor(0).emit_points()
+    assert e.value.code == pkg._abi.ERR_STATE
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    prm = pkg.make_params(85, **kw)
+    pts, cells, poff = [], [], 0
+    for a, b in zip([0, 11, 25], [11, 25, nz]):
+        lo, hi = max(a - 8, 0), min(b + 8, nz)
+        slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+        n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo)), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        extractor.emit_points()
+        extractor.emit_points()                              # harmless twice
+        torch.cuda.synchronize()
+        extractor.emit(poff, 0)
+        m = extractor.download()
+        assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
