@@ -108,6 +108,12 @@ typedef struct {
   int32_t reserved;
   int64_t lowest_occupied_z;         /* global z of the lowest / highest owned slice holding an inside voxel, -1: none */
   int64_t highest_occupied_z;
+  int64_t second_highest_occupied_z; /* the owned occupied slice below highest_occupied_z, -1: none (the source when the
+                                        slice the rank above asks about is this rank's highest one: its ghost slice) */
+  int64_t alias_z;                   /* global z of the slice the flag is about: the first occupied slice of the counted
+                                        range (own_z0 - 1, the ghost slice, included); -1 without the flag.  Its source is
+                                        the highest occupied slice STRICTLY below it that any rank owns.  When alias_z is
+                                        the ghost slice only the source's bits are needed (cuberille_recount), no plane */
 } cuberille_slab_status;
 
 typedef struct {

@@ -47,7 +47,7 @@ class Slab(C.Structure):
 
 class SlabStatus(C.Structure):
     _fields_ = [("alias_source_below_buffer", C.c_int32), ("reserved", C.c_int32), ("lowest_occupied_z", C.c_int64),
-                ("highest_occupied_z", C.c_int64)]
+                ("highest_occupied_z", C.c_int64), ("second_highest_occupied_z", C.c_int64), ("alias_z", C.c_int64)]
 
 
 class Result(C.Structure):

@@ -66,6 +66,7 @@ struct cuberille_ctx {
   hipEvent_t stageFree[2] = {}, chunkIn[2] = {};
   bool aliasBelowBuffer = false;         // soft condition of the last slab count (cuberille_slab_info)
   bool aliasMustResolve = false;         // ... and it is certain: the source slice lies in this slab's own halo
+  int aliasZ = -1;                       // local slice whose Q1 source is unresolved (the first occupied counted slice), -1
   bool slabMode = false;                 // the last count was given a slab
   u64 pointOffset = 0;                   // of the last emit
   const u64 *extIds = nullptr;           // cuberille_set_alias_plane: planes for the next emit (device pointers)
@@ -285,6 +286,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->haveMesh = false;
   c->aliasBelowBuffer = false;
   c->aliasMustResolve = false;
+  c->aliasZ = -1;
   HIP_TRY(c, hipSetDevice(c->device));
 
   // ---- layout -----------------------------------------------------------------------------
@@ -398,6 +400,10 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
   // cuberille_recount), possible when the search ran off the buffer's bottom (the ranks below know)
   c->aliasMustResolve = (c->tot.err & ERRF_ALIAS_UNKNOWN) != 0;
   c->aliasBelowBuffer = (c->tot.err & (ERRF_ALIAS_BELOW_BUFFER | ERRF_ALIAS_UNKNOWN)) != 0;
+  // the slice it concerns: only the FIRST occupied slice of the counted range can have its source outside of it
+  if (c->slabMode && c->aliasZ < 0 && c->aliasBelowBuffer)
+    for (int z = g.cz0; z < g.oz1; z++)
+      if (c->hostOcc[(size_t)z]) { c->aliasZ = z; break; }
   c->counted = true;
   std::memset(&c->res, 0, sizeof(c->res));
   c->res.n_points = c->tot.totV - c->tot.V0;
@@ -562,7 +568,9 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   int rc = emit_preconditions(c, "cuberille_emit");
   if (rc) return rc;
-  if (c->g.extAlias && (!c->extIds || !c->extPts))
+  // (a recount for the ghost slice needed the source's bits only: that slice emits no cells)
+  const bool needPlane = c->g.extAlias && c->aliasZ >= c->g.oz0;
+  if (needPlane && (!c->extIds || !c->extPts))
     return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
   (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
   c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
@@ -571,12 +579,12 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   if (rc) return rc;
   const u64 nV = c->tot.totV;
   const u64 nQ = c->tot.totQ - c->tot.Q0;
-  const size_t planeCorners = c->g.extAlias ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
+  const size_t planeCorners = needPlane ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
   Workspace &w = c->w;
   hipStream_t s = c->stream;
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, c->extIds, s));
+  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -770,12 +778,14 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
     return fail(c, CUBERILLE_ERR_STATE, "no counted slab on this context");
   out->alias_source_below_buffer = c->aliasBelowBuffer ? 1 : 0;
   out->reserved = 0;
-  out->lowest_occupied_z = out->highest_occupied_z = -1;
+  out->lowest_occupied_z = out->highest_occupied_z = out->second_highest_occupied_z = -1;
   for (int z = c->g.oz0; z < c->g.oz1; z++)
     if (c->hostOcc[(size_t)z]) {
       if (out->lowest_occupied_z < 0) out->lowest_occupied_z = c->g.zglob0 + z;
+      out->second_highest_occupied_z = out->highest_occupied_z;
       out->highest_occupied_z = c->g.zglob0 + z;
     }
+  out->alias_z = c->aliasZ >= 0 ? c->g.zglob0 + c->aliasZ : -1;
   return CUBERILLE_OK;
 }
 

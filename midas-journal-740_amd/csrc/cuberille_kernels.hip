@@ -311,17 +311,19 @@ __global__ __launch_bounds__(256) void k_occupancy(const u64 *__restrict__ bits,
 // [cz0, ..) -- its ids belong to the rank below -- or the search fell off the bottom of a slab buffer that does not
 // start at the volume's first slice (the multi-GPU driver knows whether anything is occupied down there).  Either
 // way the rank below can hand the source slice over (Grid::extAlias, cuberille_recount).
+// The ghost slice (cz0 when cz0 < oz0: counted for its vertex ids only, it emits no cells) needs nothing but the
+// source's inside BITS -- which bottom corners it does not create -- so a source anywhere in the buffer serves it;
+// only a source below the buffer has to be handed over, and then the bits alone.
 __device__ __forceinline__ int alias_of(const u32 *__restrict__ occ, const Grid &g, int q1, int z, u32 &unknown) {
   unknown = 0;
   if (!q1 || z <= 0 || occ[z - 1]) return -1;
   int p = z - 2;
   while (p >= 0 && !occ[p]) p--;
-  if ((p >= 0 && p < g.cz0 && z >= g.cz0) || (p < 0 && g.zglob0 > 0)) {
-    if (g.extAlias) return g.nzb;      // the source slice came from the rank below: it sits one past the buffer
-    unknown = p >= 0 ? ERRF_ALIAS_UNKNOWN : ERRF_ALIAS_BELOW_BUFFER;
-    return -1;
-  }
-  return p;
+  if (p >= 0 && (p >= g.cz0 || z < g.oz0)) return p;
+  if (p < 0 && g.zglob0 == 0) return -1;
+  if (g.extAlias) return g.nzb;        // the source slice came from a rank below: it sits one past the buffer
+  unknown = p >= 0 ? ERRF_ALIAS_UNKNOWN : ERRF_ALIAS_BELOW_BUFFER;
+  return -1;
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP data path (no LDS round trips, unlike __shfl_up):

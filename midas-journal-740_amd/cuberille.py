@@ -9,6 +9,7 @@ layer over the C ABI (include/cuberille_hip.h) used by bench.py and the multi-GP
 driver.  Everything computes on the GPU through libcuberille_hip.so; nothing here
 falls back to a CPU implementation.
 """
+import collections
 import ctypes as C
 import os
 
@@ -69,6 +70,8 @@ class Mesh:
         if rc != _abi.OK:
             raise _abi.CuberilleError(rc, "cannot write %s" % path)
 
+
+SlabInfo = collections.namedtuple("SlabInfo", "alias_below lowest highest second_highest alias_z")
 
 PROJECT_DEFAULT, PROJECT_ADVANCED, PROJECT_LINESEARCH = 0, 1, 2    # include/cuberille_hip.h CUBERILLE_PROJECT_*
 
@@ -241,10 +244,12 @@ class Extractor:
         return occ != 0
 
     def slab_info(self):
-        """After count() on a slab: (alias_source_below_buffer, lowest_occupied_z, highest_occupied_z)."""
+        """After count() on a slab: SlabInfo(alias_below, lowest, highest, second_highest, alias_z) -- the fields of
+        cuberille_slab_status (global slices, -1 = none)."""
         st = _abi.SlabStatus()
         _abi.check(self._ctx, self._lib.cuberille_slab_info(self._ctx, C.byref(st)))
-        return bool(st.alias_source_below_buffer), int(st.lowest_occupied_z), int(st.highest_occupied_z)
+        return SlabInfo(bool(st.alias_source_below_buffer), int(st.lowest_occupied_z), int(st.highest_occupied_z),
+                        int(st.second_highest_occupied_z), int(st.alias_z))
 
     # -- quirk Q1 across a slab boundary (include/cuberille_hip.h) ------------------------------------------------
     def slice_bits_device(self, z_global):

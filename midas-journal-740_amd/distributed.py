@@ -121,6 +121,15 @@ class _DeviceArray:
                                          "version": 2}
 
 
+def _words_view(ptr, n, device):
+    """n int64 words at `ptr` as a tensor without copying (device memory; host memory for the CPU stand-ins of the tests)."""
+    import torch
+    if device.type == "cpu":
+        import ctypes
+        return torch.frombuffer((ctypes.c_int64 * n).from_address(ptr), dtype=torch.int64)
+    return torch.as_tensor(_DeviceArray(ptr, (n,), "<i8"), device=device)
+
+
 def mesh_tensors(extractor, device):
     """The last mesh part of `extractor` as torch tensors WITHOUT copying: points float32 [n,3], cells int64 [m,k]
     (the uint64 ids reinterpreted; they are < 2^63).  Valid until the next call on the extractor."""
@@ -141,17 +150,32 @@ def id_offsets(counts, rank):
     return int(c[:rank, 0].sum()), int(c[:rank, 1].sum())
 
 
-def alias_plan(rows):
-    """From the gathered per-rank rows [n_points, n_cells, alias_source_below_buffer, highest_occupied_z, failed]:
-    the (consumer rank, source rank, source slice) triples of quirk Q1 crossing slab boundaries.  A rank whose first
-    occupied slice has nothing but empty slices below it in its buffer re-uses the vertices of the highest occupied
-    slice any rank below it owns (ranks in between hold no occupied slice at all)."""
+# columns of the per-rank row that travels in the count all-gather
+ROW_POINTS, ROW_CELLS, ROW_ALIAS_Z, ROW_TOP, ROW_TOP2, ROW_FAILED = range(6)
+
+
+def alias_plan(rows, bounds=None):
+    """From the gathered per-rank rows [n_points, n_cells, alias_z, highest occupied owned slice, second highest,
+    failed]: the (consumer rank, source rank, source slice, plane needed) entries of quirk Q1 crossing slab boundaries.
+    alias_z >= 0 on rank r: the first occupied slice of r's counted range (its ghost slice own_z0 - 1 included) has
+    nothing but empty slices below it in r's buffer, so the reference would re-use the vertices of the highest occupied
+    slice STRICTLY below alias_z -- owned by some rank below r -- if there is one.  When alias_z is the ghost slice
+    (it is the highest occupied slice of the rank below, so that rank's SECOND highest one is the candidate there) the
+    consumer needs the source's inside bits only: it emits no cells for that slice.  bounds: the ranks' (z0, z1)."""
     plan = []
     rows = np.asarray(rows)
     for r in range(1, rows.shape[0]):
-        if rows[r, 2] and (rows[:r, 3] >= 0).any():
-            src = int(np.argmax(rows[:r, 3]))
-            plan.append((r, src, int(rows[src, 3])))
+        az = int(rows[r, ROW_ALIAS_Z])
+        if az < 0:
+            continue
+        src, zp = -1, -1
+        for s in range(r):
+            h = int(rows[s, ROW_TOP]) if rows[s, ROW_TOP] < az else int(rows[s, ROW_TOP2])
+            if h >= 0 and h < az and h > zp:
+                src, zp = s, h
+        if src >= 0:
+            ghost = bounds is not None and az < bounds[r][0]
+            plan.append((r, src, zp, not ghost))
     return plan
 
 
@@ -270,69 +294,104 @@ class ShardedExtractor:
             return self.ex.emit(0, 0)
         # a failure on one rank must not leave the others waiting in the all-gather: it travels with the counts
         n_p = n_c = 0
-        soft, top, failed = False, -1, None
+        info, failed = None, None
         try:
             n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab)
             if self.check_aliasing and params.emulate_empty_slice_aliasing:
-                soft, _, top = self.ex.slab_info()
-            if not soft:
+                info = self.ex.slab_info()
+            if info is None or info.alias_z < 0:
                 # nothing another rank says can change this rank's counts: the vertices are scattered and projected
                 # while the counts are gathered, only the cells wait for the id offsets
                 self.ex.emit_points()
         except _abi.CuberilleError as e:
             failed = e
         del keep
-        rows = gather_counts(n_p, n_c, buf.device, self.group, extra=(int(soft), top, 0 if failed is None else 1))
+        dev = buf.device
+        rows = gather_counts(n_p, n_c, dev, self.group, extra=(
+            info.alias_z if info is not None else -1, info.highest if info is not None else -1,
+            info.second_highest if info is not None else -1, 0 if failed is None else 1))
         self.counts = rows[:, :2]
-        if rows[:, 4].any():
-            bad = [int(r) for r in np.nonzero(rows[:, 4])[0]]
-            raise RuntimeError("cuberille_count failed on rank(s) %s%s" % (bad, ": %s" % failed if failed is not None else ""))
+        self._raise_if_any_failed(rows[:, ROW_FAILED], "cuberille_count", failed)
         # quirk Q1 across slab boundaries: rank r assumed that nothing is occupied below its buffer; a rank below says
         # otherwise.  Every rank derives the same plan from the gathered rows.
-        plan = alias_plan(rows) if self.check_aliasing else []
+        bounds = [slab_range(self.nz, self.world, r) for r in range(self.world)]
+        plan = alias_plan(rows, bounds) if self.check_aliasing else []
         if plan and not self.cross_slab_aliasing:
             raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % plan[0][0])
-        dev = buf.device
         n_words = self.ny * ((self.nx + 63) // 64)
         n_corners = (self.nx + 1) * (self.ny + 1)
-        for r, src, zp in plan:
+        for r, src, zp, _ in plan:
             # the consumer counts again with the source slice's inside bits at hand: the re-used vertices are no
-            # longer created
+            # longer created.  A rank that fails here still takes part in every transfer of the plan (nobody waits
+            # for a message that never comes); the failure travels in the second gather and is raised everywhere.
             if self.rank == src:
-                ptr, n = self.ex.slice_bits_device(zp)
-                _p2p_send(torch.as_tensor(_DeviceArray(ptr, (n,), "<i8"), device=dev), r, self.group)
+                try:
+                    ptr, n = self.ex.slice_bits_device(zp)
+                    bits = _words_view(ptr, n, dev)
+                except _abi.CuberilleError as e:
+                    failed = failed or e
+                    bits = torch.zeros((n_words,), dtype=torch.int64, device=dev)
+                _p2p_send(bits, r, self.group)
             if self.rank == r:
                 bits = _p2p_recv((n_words,), torch.int64, dev, src, self.group)
                 if dev.type == "cuda":
                     torch.cuda.current_stream().synchronize()
-                n_p, n_c = self.ex.recount(bits.data_ptr())
+                try:
+                    n_p, n_c = self.ex.recount(bits.data_ptr())
+                except _abi.CuberilleError as e:
+                    failed = failed or e
                 del bits
         if plan:
-            self.counts = gather_counts(n_p, n_c, dev, self.group)
+            rows2 = gather_counts(n_p, n_c, dev, self.group, extra=(0 if failed is None else 1,))
+            self.counts = rows2[:, :2]
+            self._raise_if_any_failed(rows2[:, 2], "cuberille_recount", failed)
         poff, coff = id_offsets(self.counts, self.rank)
-        mine = [e for e in plan if e[0] == self.rank]
-        serve = [e for e in plan if e[1] == self.rank]
-        planes = None
-        if mine:
-            # ids and final positions of the vertices under the (x, y) corner keys of the source slice's top plane
-            _, src, _ = mine[0]
-            ids = _p2p_recv((n_corners,), torch.int64, dev, src, self.group)
-            pts = _p2p_recv((n_corners, 3), torch.float32, dev, src, self.group)
-            if dev.type == "cuda":
-                torch.cuda.current_stream().synchronize()
-            self.ex.set_alias_plane(ids.data_ptr(), pts.data_ptr())
-            planes = (ids, pts)
-        res = self.ex.emit(poff, coff)
+        mine = [e for e in plan if e[0] == self.rank and e[3]]
+        serve = [e for e in plan if e[1] == self.rank and e[3]]
+        planes, res = None, None
+        try:
+            if mine:
+                # ids and final positions of the vertices under the (x, y) corner keys of the source slice's top plane
+                # (a plane whose first id is -2 says that the serving rank failed)
+                _, src, _, _ = mine[0]
+                ids = _p2p_recv((n_corners,), torch.int64, dev, src, self.group)
+                pts = _p2p_recv((n_corners, 3), torch.float32, dev, src, self.group)
+                if dev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+                if n_corners and int(ids[0]) == -2:
+                    raise RuntimeError("the rank serving the re-used vertices (rank %d) failed" % src)
+                self.ex.set_alias_plane(ids.data_ptr(), pts.data_ptr())
+                planes = (ids, pts)
+            res = self.ex.emit(poff, coff)
+        except (_abi.CuberilleError, RuntimeError) as e:
+            failed = failed or e
         del planes
-        for r, _, zp in serve:
+        for r, _, zp, _ in serve:
             ids = torch.empty((n_corners,), dtype=torch.int64, device=dev)
-            pts = torch.empty((n_corners, 3), dtype=torch.float32, device=dev)
+            pts = torch.zeros((n_corners, 3), dtype=torch.float32, device=dev)
             if dev.type == "cuda":
                 torch.cuda.current_stream().synchronize()
-            self.ex.alias_plane_device(zp, ids.data_ptr(), pts.data_ptr())
+            try:
+                if failed is not None:
+                    raise failed
+                self.ex.alias_plane_device(zp, ids.data_ptr(), pts.data_ptr())
+            except (_abi.CuberilleError, RuntimeError) as e:
+                failed = failed or e
+                ids.fill_(-2)
             _p2p_send(ids, r, self.group)
             _p2p_send(pts, r, self.group)
+        if plan:
+            # the hand-over made ranks depend on each other after the counts were agreed: close the step together
+            ok = gather_counts(0, 0, dev, self.group, extra=(0 if failed is None else 1,))
+            self._raise_if_any_failed(ok[:, 2], "cuberille_emit", failed)
+        elif failed is not None:
+            raise failed
         return res
+
+    def _raise_if_any_failed(self, flags, what, mine):
+        if np.asarray(flags).any():
+            bad = [int(r) for r in np.nonzero(np.asarray(flags))[0]]
+            raise RuntimeError("%s failed on rank(s) %s%s" % (what, bad, ": %s" % mine if mine is not None else ""))
 
     def gather_mesh(self, dst=0, on_device=None):
         """Concatenate the rank parts in rank order on rank `dst` (collective 3): the

@@ -89,18 +89,30 @@ def test_halo_exchange_and_offsets_gloo(tmp_path, world, nz):
 
 
 def test_alias_plan():
-    """Who serves whom when quirk Q1 crosses slab boundaries: rows = [points, cells, alias source below buffer,
-    highest occupied slice, failed] per rank."""
+    """Who serves whom when quirk Q1 crosses slab boundaries: rows = [points, cells, alias_z, highest occupied slice,
+    second highest, failed] per rank; entries (consumer, source, source slice, plane needed)."""
     import sys
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
     graft.load_package()
     from midas_journal_740_amd import distributed as D
-    assert D.alias_plan([[5, 5, 0, 30, 0], [5, 5, 0, 60, 0]]) == []
-    assert D.alias_plan([[5, 5, 0, 30, 0], [5, 5, 1, 60, 0]]) == [(1, 0, 30)]
-    assert D.alias_plan([[0, 0, 0, -1, 0], [5, 5, 1, 60, 0]]) == []                    # nothing occupied below
+    assert D.alias_plan([[5, 5, -1, 30, 29, 0], [5, 5, -1, 60, 59, 0]]) == []
+    assert D.alias_plan([[5, 5, -1, 30, 29, 0], [5, 5, 60, 60, 59, 0]]) == [(1, 0, 30, True)]
+    assert D.alias_plan([[0, 0, -1, -1, -1, 0], [5, 5, 60, 60, -1, 0]]) == []                    # nothing occupied below
     # an empty rank in between: rank 2 re-uses rank 0's vertices; rank 3 those of rank 2
-    assert D.alias_plan([[5, 5, 0, 10, 0], [0, 0, 0, -1, 0], [5, 5, 1, 40, 0], [5, 5, 1, 70, 0]]) == [(2, 0, 10), (3, 2, 40)]
+    assert D.alias_plan([[5, 5, -1, 10, 9, 0], [0, 0, -1, -1, -1, 0], [5, 5, 40, 40, -1, 0], [5, 5, 70, 70, -1, 0]]) == \
+        [(2, 0, 10, True), (3, 2, 40, True)]
+    # the aliased slice is rank 1's GHOST slice 19 (rank 0's highest): the source is the highest occupied slice strictly
+    # below it -- rank 0's second highest -- and only its bits are needed (round-2 advisor finding: the old plan took
+    # slice 19 itself)
+    b = [(0, 20), (20, 40)]
+    assert D.alias_plan([[5, 5, -1, 19, 4, 0], [5, 5, 19, 30, 29, 0]], b) == [(1, 0, 4, False)]
+    # ... and nothing to do when slice 19 is the lowest occupied slice of the volume
+    assert D.alias_plan([[5, 5, -1, 19, -1, 0], [5, 5, 19, 30, 29, 0]], b) == []
+    # three ranks, the source two ranks down
+    b = [(0, 10), (10, 20), (20, 30)]
+    assert D.alias_plan([[5, 5, -1, 3, 2, 0], [5, 5, 19, 19, -1, 0], [5, 5, 19, 25, 24, 0]], b) == \
+        [(1, 0, 3, True), (2, 0, 3, False)]
 
 
 def test_halo_transfers_cover_the_halo_exactly():
@@ -182,12 +194,13 @@ def _fake_worker(rank, world, port, scenario, out_dir):
             return 100 + rank, 7 * (rank + 1)
 
         def slab_info():
-            # (alias source below the buffer, lowest, highest occupied owned slice)
-            if scenario == "alias":
-                return (rank == 1, 0, 5 if rank == 0 else 30)
+            # (alias source below the buffer, lowest, highest, second highest occupied owned slice, aliased slice)
+            SI = pkg.cuberille.SlabInfo
+            if scenario in ("alias", "recount_fails"):
+                return SI(rank == 1, 0, 5 if rank == 0 else 30, 4 if rank == 0 else 29, 25 if rank == 1 else -1)
             if scenario == "alias_nothing_below":
-                return (rank == 1, -1, -1 if rank == 0 else 30)
-            return (False, 0, nz - 1)
+                return SI(rank == 1, -1, -1 if rank == 0 else 30, -1 if rank == 0 else 29, 25 if rank == 1 else -1)
+            return SI(False, 0, nz - 1, nz - 2, -1)
 
         def emit(poff, coff):
             calls["offsets"] = (poff, coff)
@@ -195,11 +208,23 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         def emit_points():
             # only a rank whose counts nothing can change may start early
             calls["early"] = True
-            assert not slab_info()[0]
-        fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, emit_points=emit_points, result=None)
+            assert slab_info().alias_z < 0
+
+        def slice_bits_device(zp):
+            calls["served_bits"] = zp
+            keep = torch.zeros(ny * ((nx + 63) // 64), dtype=torch.int64)
+            calls["keep"] = keep
+            return keep.data_ptr(), keep.numel()
+
+        def recount(ptr):
+            raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic recount failure")
+        fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, emit_points=emit_points, result=None,
+                                     slice_bits_device=slice_bits_device, recount=recount)
         prm = pkg.make_params(0.5)
-        # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused)
-        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm, cross_slab_aliasing=False)
+        # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused, or,
+        #  "recount_fails", taken up to the consumer's recount, which fails: every rank must raise, none may hang)
+        sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm,
+                                cross_slab_aliasing=scenario == "recount_fails")
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx))
         err = ""
@@ -219,7 +244,7 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below"])
+@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails"])
 def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
     (nobody is left waiting in the all-gather); quirk Q1 crossing the slab boundary is refused exactly when a rank
@@ -232,6 +257,8 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
         assert rows[0][1] == "(0, 0)" and rows[1][1] == "(100, 7)"
         assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 12, 20, 40)"
     elif scenario == "fail":
-        assert all("failed on rank(s) [1]" in r[0] for r in rows)
+        assert all("cuberille_count failed on rank(s) [1]" in r[0] for r in rows)
+    elif scenario == "recount_fails":
+        assert all("cuberille_recount failed on rank(s) [1]" in r[0] for r in rows)
     else:
         assert all("quirk Q1" in r[0] and "below rank 1" in r[0] for r in rows)
