@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 8
+#define CUBERILLE_ABI_VERSION 9
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -44,13 +44,20 @@ enum {
   CUBERILLE_ERR_STATE = 4,      /* call order violated (emit before count, ...) */
   CUBERILLE_ERR_HALO = 5,       /* slab does not carry the halo the owned range needs */
   CUBERILLE_ERR_LIMIT = 6,      /* volume exceeds an implementation limit */
-  CUBERILLE_ERR_SOURCE = 7      /* the chunk source of cuberille_extract_stream reported a failure */
+  CUBERILLE_ERR_SOURCE = 7,     /* the chunk source of cuberille_extract_stream reported a failure */
+  CUBERILLE_RETRY = 8           /* cuberille_emit_device_offsets only: not an error -- some rank raised a flag (quirk Q1
+                                   across slabs, a buffer too small, a walk that left a thin halo); nothing was emitted,
+                                   the count stands, continue with the synchronous calls */
 };
 
-/* InputPixelType of the filter (h:150).  Same numbering as the oracle. */
+/* InputPixelType of the filter (h:150: any pixel type the template is instantiated with).  Same numbering as the
+ * oracle.  The 64-bit integer types (long / unsigned long / long long on LP64) compare in their own type (txx:139-141)
+ * and enter the walk the way ITK's operators take them: through (float) in the gradient taps (I6), through (double)
+ * in the interpolation (I5) -- both round to nearest for magnitudes past 2^24 / 2^53. */
 enum {
   CUBERILLE_PIX_U8 = 0, CUBERILLE_PIX_I8 = 1, CUBERILLE_PIX_U16 = 2, CUBERILLE_PIX_I16 = 3,
-  CUBERILLE_PIX_U32 = 4, CUBERILLE_PIX_I32 = 5, CUBERILLE_PIX_F32 = 6, CUBERILLE_PIX_F64 = 7
+  CUBERILLE_PIX_U32 = 4, CUBERILLE_PIX_I32 = 5, CUBERILLE_PIX_F32 = 6, CUBERILLE_PIX_F64 = 7,
+  CUBERILLE_PIX_I64 = 8, CUBERILLE_PIX_U64 = 9
 };
 
 /* The input image: replaces itk::Image::{GetBufferedRegion, GetSpacing, GetOrigin,
@@ -80,6 +87,8 @@ typedef struct {
                                     (USE_LINESEARCH_PROJECTION, txx:398-437) -- the last two are compiled out upstream
                                     (h:22-23); anything else is CUBERILLE_ERR_ARGUMENT */
   int32_t reserved;              /* 0 */
+  int64_t iso_value_int;         /* CUBERILLE_PIX_I64 / _U64 only (iso_value is then ignored): the iso value itself, which a
+                                    double cannot hold past 2^53; for _U64 the same 64 bits read as unsigned */
 } cuberille_params;
 
 enum { CUBERILLE_PROJECT_DEFAULT = 0, CUBERILLE_PROJECT_ADVANCED = 1, CUBERILLE_PROJECT_LINESEARCH = 2 };
@@ -90,13 +99,22 @@ typedef struct {
   int64_t global_nz;        /* Nz of the whole volume */
   int64_t z_begin;          /* global z of the buffer's first slice */
   int64_t own_z0, own_z1;   /* global slices [own_z0, own_z1) this rank emits */
-  uint64_t point_id_offset; /* ids of this rank's first point / first cell; set them */
-  uint64_t cell_id_offset;  /*   with cuberille_emit after the count all-gather */
+  uint64_t point_id_offset; /* id of this rank's first point (cuberille_extract_device; the two-call form passes it to
+                               cuberille_emit after the count all-gather).  Cells need no offset: a cell's id is its
+                               position in the rank-ordered concatenation, no buffer holds it */
+  uint64_t flags;           /* CUBERILLE_SLAB_* */
   void *halo_ready_event;   /* optional hipEvent_t recorded behind the halo exchange: cuberille_count
                                thresholds the owned slices at once and the halo slices after it */
   void *voxels_ready_event; /* optional hipEvent_t recorded on the stream that produced the OWNED slices:
                                nothing of the buffer is read before it (the context runs on its own stream) */
 } cuberille_slab;
+
+/* cuberille_slab::flags.  THIN_HALO: the buffer holds fewer slices around the owned range than the projection walk
+ * could reach (cuberille_required_halo) but at least what every vertex needs where it STARTS (cuberille_minimum_halo).
+ * A walk that then asks for a slice the buffer lacks (and the volume has) is not clamped: the vertex is put aside,
+ * cuberille_result::n_escaped counts it, and cuberille_reproject_escaped walks those vertices again once the caller
+ * has the deeper halo -- the neighbours' slices cross the links only when some walk really needed them. */
+enum { CUBERILLE_SLAB_THIN_HALO = 1 };
 
 /* What a multi-GPU driver needs to know about the last cuberille_count of a slab besides the counts
  * (it travels in the same all-gather): quirk Q1 re-uses vertices across EMPTY slices, so a rank whose
@@ -130,9 +148,19 @@ typedef struct {
   float ms_emit_points;     /* vertex scatter: AddVertex without the projection (txx:256-276) */
   float ms_project;         /* vertex projection (txx:439-474) */
   float ms_emit_cells;      /* quad / triangle scatter incl. the diagonal split (txx:278-332) */
-  float ms_total;           /* ms_pass + the emit phase (points, projection, cells); not the host round trip between them */
-  float ms_pass;            /* classify + count + scan: the pass over the volume (sits in what was padding before ABI 7) */
+  float ms_total;           /* ms_pass + the emit phase (points, projection, cells).  When cuberille_emit_points started the
+                               vertex phase ahead of cuberille_emit, the two phases are timed as intervals of their own and
+                               added: the device's wait for the host's all-gather in between is in neither */
+  float ms_pass;            /* classify + count + scan: the pass over the volume.  cuberille_extract_host's chunked upload and
+                               cuberille_extract_stream threshold every chunk as it lands, so for those two entries the
+                               figure includes the ingestion; after cuberille_recount it is the second count alone */
   uint64_t proj_iterations; /* total iterations of the projection loop */
+  /* why the walks ended: the reference's DEBUG_PRINT counters m_ProjectVertexTerminate[0] / [1] (h:336-338; txx:457-459,
+   * 470-472, printed at txx:208-214): within the distance threshold / out of steps.  Owned vertices only; a vertex of the
+   * ADVANCED branch that stops on its oscillation rule and every vertex of the LINESEARCH branch count in neither. */
+  uint64_t proj_stop_threshold;
+  uint64_t proj_stop_steps;
+  uint64_t n_escaped;       /* THIN_HALO slabs: vertices whose walk left the buffer, waiting for cuberille_reproject_escaped */
 } cuberille_result;
 
 typedef struct cuberille_ctx cuberille_ctx;
@@ -173,8 +201,24 @@ int cuberille_extract_device(cuberille_ctx *ctx, const cuberille_image_desc *img
 int cuberille_count(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
                     const cuberille_params *prm, const cuberille_slab *slab,
                     uint64_t *n_points, uint64_t *n_cells);
-int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, uint64_t cell_id_offset,
-                   cuberille_result *res);
+int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, cuberille_result *res);
+/* The same step without a host round trip between count and emit -- the steady state of a multi-GPU driver, and the
+ * short way through a small volume.  cuberille_step_begin (arguments of cuberille_count) launches the count AND the part
+ * of the emit that needs no id offset back to back and returns without waiting: the launches behind the count are sized
+ * from what the previous extraction on this context produced (+25 %), read the real counts from device memory and run
+ * only if those fit.  (The first extraction on a context, and configurations without the scratch tables, wait for the
+ * counts once instead; the caller sees no difference.)  *dev_row: this rank's row, *row_bytes bytes of device memory
+ * that are final when the context's stream gets there.  The caller gathers the rows of all ranks, in rank order, into
+ * device memory -- stream-ordered behind this call, e.g. RCCL's all-gather on the same stream; one rank: the row itself
+ * -- and calls cuberille_step_end(rows, n_ranks, rank): the cells, with this rank's id offset summed on the device from
+ * the rows below it, then the ONE wait of the step.  CUBERILLE_OK: the mesh is in place as after cuberille_emit.
+ * CUBERILLE_RETRY: a row carries a flag -- quirk Q1 crossing a slab boundary, counts beyond the sizes guessed, a walk
+ * that left a THIN_HALO -- on SOME rank: no rank has written cells (each looks at all rows), the count stands (*res holds
+ * n_points / n_cells as cuberille_count would have returned them) and the calls above continue from it on every rank
+ * (cuberille_slab_info ... cuberille_emit). */
+int cuberille_step_begin(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
+                         const cuberille_params *prm, const cuberille_slab *slab, const void **dev_row, size_t *row_bytes);
+int cuberille_step_end(cuberille_ctx *ctx, const void *dev_rows, int n_ranks, int rank, cuberille_result *res);
 /* Optional, between the two: starts the part of the emit that needs no id offset -- head tables, vertex scatter,
  * projection -- and returns at once, so that the GPU works while the caller gathers the other ranks' counts;
  * cuberille_emit then only adds the cells.  A cuberille_recount after it voids what it started. */
@@ -184,6 +228,20 @@ int cuberille_emit_points(cuberille_ctx *ctx);
  * sum(relaxation^k, k <= max_steps+1) over the z spacing -- plus the interpolation cell and the gradient ring.
  * cuberille_count returns CUBERILLE_ERR_HALO for a buffer that holds less.  Needs no GPU. */
 int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above);
+/* The least a THIN_HALO slab must hold: 2 below / 1 above for the topology (the ghost slice own_z0 - 1 and the slice under
+ * it decide the ids on plane own_z0); with the projection on, also the cell a vertex STARTS in and its gradient ring for the
+ * vertices on planes own_z0 .. own_z1 -- 2 / 2 for an axis-aligned image (a vertex starts half a voxel under its lattice
+ * corner, txx:266-270).  Every slice more is margin a walk may use before it counts as escaped.  Needs no GPU. */
+int cuberille_minimum_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above);
+/* THIN_HALO slabs, after cuberille_emit_points: how many walks left the buffer (waits for the vertex phase; UINT64_MAX:
+ * more than the list holds).  When any rank
+ * reports some, every rank completes its halo to cuberille_required_halo and the ranks concerned call
+ * cuberille_reproject_escaped(buffer, its first global slice, its slice count) -- same pixel type, Nx, Ny and geometry as the
+ * counted slab; the counted slab's own buffer is not read again -- which walks exactly those vertices again, from their
+ * start; then cuberille_emit as usual.  More escapes than the list holds (2^20): CUBERILLE_ERR_LIMIT, count the slab again
+ * with the full halo.  cuberille_emit on a THIN_HALO slab refuses (CUBERILLE_ERR_HALO, the count stands) while walks wait. */
+int cuberille_escaped_count(cuberille_ctx *ctx, uint64_t *n_escaped);
+int cuberille_reproject_escaped(cuberille_ctx *ctx, const void *dev_voxels, int64_t z_begin, int64_t nz);
 /* After cuberille_count on a slab: see cuberille_slab_status. */
 int cuberille_slab_info(cuberille_ctx *ctx, cuberille_slab_status *out);
 

@@ -13,7 +13,9 @@ CSRC = os.path.join(_HERE, "csrc")
 # CUBERILLE_LIB: load another build of the same ABI (same-box A/B timing of kernel changes)
 LIB_PATH = os.environ.get("CUBERILLE_LIB") or os.path.join(CSRC, "libcuberille_hip.so")
 
-OK, ERR_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_HALO, ERR_LIMIT, ERR_SOURCE = range(8)
+OK, ERR_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_HALO, ERR_LIMIT, ERR_SOURCE, RETRY = range(9)
+SLAB_THIN_HALO = 1
+ESCAPED_OVERFLOW = 1 << 62          # Extractor.escaped_count(): more walks escaped than the library's list holds
 
 # every symbol include/cuberille_hip.h declares (tests check the built library exports them all)
 EXPORTS = [
@@ -23,8 +25,9 @@ EXPORTS = [
     "cuberille_debug_bits", "cuberille_slice_occupancy", "cuberille_write_vtk_buffers", "cuberille_mesh_write_vtk",
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
+    "cuberille_minimum_halo", "cuberille_escaped_count", "cuberille_reproject_escaped", "cuberille_step_begin", "cuberille_step_end",
 ]
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ImageDesc(C.Structure):
@@ -36,12 +39,12 @@ class Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
                 ("max_steps", C.c_uint32), ("emulate_empty_slice_aliasing", C.c_int32),
-                ("projection_variant", C.c_int32), ("reserved", C.c_int32)]
+                ("projection_variant", C.c_int32), ("reserved", C.c_int32), ("iso_value_int", C.c_int64)]
 
 
 class Slab(C.Structure):
     _fields_ = [("global_nz", C.c_int64), ("z_begin", C.c_int64), ("own_z0", C.c_int64), ("own_z1", C.c_int64),
-                ("point_id_offset", C.c_uint64), ("cell_id_offset", C.c_uint64), ("halo_ready_event", C.c_void_p),
+                ("point_id_offset", C.c_uint64), ("flags", C.c_uint64), ("halo_ready_event", C.c_void_p),
                 ("voxels_ready_event", C.c_void_p)]
 
 
@@ -54,7 +57,8 @@ class Result(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_cells", C.c_uint64), ("verts_per_cell", C.c_int32),
                 ("reserved", C.c_int32), ("ms_classify", C.c_float), ("ms_count", C.c_float),
                 ("ms_scan", C.c_float), ("ms_emit_points", C.c_float), ("ms_project", C.c_float),
-                ("ms_emit_cells", C.c_float), ("ms_total", C.c_float), ("ms_pass", C.c_float), ("proj_iterations", C.c_uint64)]
+                ("ms_emit_cells", C.c_float), ("ms_total", C.c_float), ("ms_pass", C.c_float), ("proj_iterations", C.c_uint64),
+                ("proj_stop_threshold", C.c_uint64), ("proj_stop_steps", C.c_uint64), ("n_escaped", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
@@ -113,7 +117,7 @@ def lib():
     L.cuberille_extract_device.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab),
                                            C.POINTER(Result)]
     L.cuberille_count.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), u64p, u64p]
-    L.cuberille_emit.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(Result)]
+    L.cuberille_emit.argtypes = [vp, C.c_uint64, C.POINTER(Result)]
     L.cuberille_emit_points.argtypes = [vp]
     L.cuberille_mesh_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cuberille_mesh_download.argtypes = [vp, vp, vp]
@@ -123,6 +127,12 @@ def lib():
     L.cuberille_mesh_write_vtk.argtypes = [vp, C.c_char_p, C.c_int]
     L.cuberille_required_halo.argtypes = [C.POINTER(ImageDesc), C.POINTER(Params), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.cuberille_slab_info.argtypes = [vp, C.POINTER(SlabStatus)]
+    L.cuberille_minimum_halo.argtypes = [C.POINTER(ImageDesc), C.POINTER(Params), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cuberille_escaped_count.argtypes = [vp, u64p]
+    L.cuberille_reproject_escaped.argtypes = [vp, vp, C.c_int64, C.c_int64]
+    L.cuberille_step_begin.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), C.POINTER(vp),
+                                       C.POINTER(C.c_size_t)]
+    L.cuberille_step_end.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
     L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cuberille_debug_h2d_seconds.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double)]
     L.cuberille_slice_bits_device.argtypes = [vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -53,7 +53,7 @@ struct cuberille_ctx {
   int device = 0;
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
-  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue;
+  DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue, escList;
   Totals *hostTotals = nullptr;          // pinned
   uint32_t *hostOcc = nullptr;           // pinned mirror of the per-slice occupancy of the last slab count
   size_t hostOccCap = 0;
@@ -68,6 +68,16 @@ struct cuberille_ctx {
   bool aliasMustResolve = false;         // ... and it is certain: the source slice lies in this slab's own halo
   int aliasZ = -1;                       // local slice whose Q1 source is unresolved (the first occupied counted slice), -1
   bool slabMode = false;                 // the last count was given a slab
+  bool thinHalo = false;                 // ... with CUBERILLE_SLAB_THIN_HALO: walks that leave the buffer are put aside
+  bool pointsStartedEarly = false;       // cuberille_emit_points ran ahead of cuberille_emit (two device intervals to add up)
+  bool escapeChecked = false;            // THIN_HALO: the number of escaped walks of the current vertex phase has been read back
+  // cuberille_step_begin / _end: what the previous extraction on this context produced sizes the blind launches
+  bool haveHistory = false;
+  u64 histV = 0, histQ = 0;
+  u32 histVW = 0;
+  int stepMode = 0;                      // 0: no step open; 1: launched blindly (sizes on the device); 2: sized by a host read
+  Totals *hostRows = nullptr;            // pinned: the gathered totals of all ranks, read back by cuberille_step_end
+  size_t hostRowsCap = 0;
   u64 pointOffset = 0;                   // of the last emit
   const u64 *extIds = nullptr;           // cuberille_set_alias_plane: planes for the next emit (device pointers)
   const float *extPts = nullptr;
@@ -110,7 +120,7 @@ size_t pixel_size(int pt) {
     case CUBERILLE_PIX_U8: case CUBERILLE_PIX_I8: return 1;
     case CUBERILLE_PIX_U16: case CUBERILLE_PIX_I16: return 2;
     case CUBERILLE_PIX_U32: case CUBERILLE_PIX_I32: case CUBERILLE_PIX_F32: return 4;
-    case CUBERILLE_PIX_F64: return 8;
+    case CUBERILLE_PIX_F64: case CUBERILLE_PIX_I64: case CUBERILLE_PIX_U64: return 8;
   }
   return 0;
 }
@@ -211,10 +221,11 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (c->own) (void)hipStreamSynchronize(c->own);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
-                    &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue};
+                    &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->escList};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   if (c->hostOcc) (void)hipHostFree(c->hostOcc);
+  if (c->hostRows) (void)hipHostFree(c->hostRows);
   for (int i = 0; i < 2; i++) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
     if (c->stageFree[i]) (void)hipEventDestroy(c->stageFree[i]);
@@ -267,6 +278,9 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
     for (int k = 0; k < 3; k++) geo.i2p[r * 3 + k] = geo.dir[r * 3 + k] * geo.spacing[k];
   invert3(geo.i2p, geo.p2i);
   p.iso = prm->iso_value;
+  p.isoInt = (long long)prm->iso_value_int;
+  if (img->pixel_type == CUBERILLE_PIX_I64) p.iso = (double)prm->iso_value_int;          // what the walk compares with
+  if (img->pixel_type == CUBERILLE_PIX_U64) p.iso = (double)(uint64_t)prm->iso_value_int;
   p.thr = prm->distance_threshold;
   p.step = prm->step_length < 0.0 ? maxSpacing * 0.25 : prm->step_length;
   p.relax = prm->relaxation;
@@ -284,6 +298,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->counted = false;
   c->pointsEmitted = false;
   c->haveMesh = false;
+  c->stepMode = 0;
   c->aliasBelowBuffer = false;
   c->aliasMustResolve = false;
   c->aliasZ = -1;
@@ -312,7 +327,11 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
     // the owned range needs 2 slices below (ids of corners created one slice down depend on the
     // slice below that) and 1 above; with the projection on, as far as a walk can reach (both unless the
     // volume ends there)
-    long long halo = projection_reach(geo, p);
+    // (a THIN_HALO slab promises the topology's slices only; walks that want more are put aside, not clamped)
+    const bool thin = (slab->flags & CUBERILLE_SLAB_THIN_HALO) != 0;
+    if (thin && p.project && p.variant != CUBERILLE_PROJECT_DEFAULT)
+      return fail(c, CUBERILLE_ERR_ARGUMENT, "a THIN_HALO slab is only offered with the default projection branch");
+    long long halo = thin ? 0 : projection_reach(geo, p);
     const long long lo = halo > 2 ? halo : 2, hi = halo > 1 ? halo : 1;
     const long long needLo = slab->own_z0 >= lo ? slab->own_z0 - lo : 0;
     const long long needHi = slab->own_z1 + hi < slab->global_nz ? slab->own_z1 + hi : slab->global_nz;
@@ -339,6 +358,9 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   // (+ one slice past the buffer: a slab may be handed the source slice of quirk Q1 from the rank below)
   HIP_TRY(c, c->bits.reserve((nwordsAll + (size_t)g.ny * g.W) * sizeof(u64)));
   c->slabMode = !whole;
+  c->thinHalo = !whole && (slab->flags & CUBERILLE_SLAB_THIN_HALO) != 0 && p.project;
+  c->pointsStartedEarly = false;
+  c->escapeChecked = false;
   c->extIds = nullptr;
   c->extPts = nullptr;
   // the totals and the per-slice occupancy share one allocation: one memset zeroes both
@@ -373,16 +395,21 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   return CUBERILLE_OK;
 }
 
-// Second half: count + scan of the thresholded volume, totals to the host.
-int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
+// Second half: count + scan of the thresholded volume (launches only).
+int count_launch(cuberille_ctx *c, const Gate &gate) {
+  hipStream_t s = c->stream;
+  if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+  HIP_TRY(c, launch_occupancy(c->w, c->g, s));
+  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, s));
+  HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  return CUBERILLE_OK;
+}
+
+// the totals (and a slab's per-slice occupancy) on their way to pinned memory
+int totals_to_host(cuberille_ctx *c) {
   hipStream_t s = c->stream;
   const Grid &g = c->g;
-  const Workspace &w = c->w;
-  if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  HIP_TRY(c, launch_occupancy(w, g, s));
-  HIP_TRY(c, launch_count(w, g, c->nwords, c->prm.q1, s));
-  HIP_TRY(c, hipEventRecord(c->ev[2], s));
-  HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(c->hostTotals, c->w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   if (c->slabMode) {
     // the slab status the multi-GPU driver asks for next rides in the same synchronisation
     if (c->hostOccCap < (size_t)g.nzb) {
@@ -392,9 +419,14 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
       HIP_TRY(c, hipHostMalloc((void **)&c->hostOcc, (size_t)g.nzb * sizeof(uint32_t), hipHostMallocDefault));
       c->hostOccCap = (size_t)g.nzb;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->hostOcc, w.sliceOcc, (size_t)g.nzb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->hostOcc, c->w.sliceOcc, (size_t)g.nzb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
-  HIP_TRY(c, hipStreamSynchronize(s));
+  return CUBERILLE_OK;
+}
+
+// ... and, once the stream has been waited for, taken over as the state of a finished count
+void adopt_totals(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
+  const Grid &g = c->g;
   c->tot = *c->hostTotals;
   // quirk Q1 reaching below this slab: certain when the source slice is in the halo (the emit then insists on
   // cuberille_recount), possible when the search ran off the buffer's bottom (the ranks below know)
@@ -411,6 +443,17 @@ int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
   c->res.verts_per_cell = c->prm.triangles ? 3 : 4;
   if (n_points) *n_points = c->res.n_points;
   if (n_cells) *n_cells = c->res.n_cells;
+}
+
+int classify_slab(cuberille_ctx *c, const cuberille_image_desc *img, const cuberille_slab *slab);
+
+int count_finish(cuberille_ctx *c, uint64_t *n_points, uint64_t *n_cells) {
+  int rc = count_launch(c, Gate{});
+  if (rc) return rc;
+  rc = totals_to_host(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  adopt_totals(c, n_points, n_cells);
   return CUBERILLE_OK;
 }
 
@@ -430,27 +473,64 @@ int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_par
   return CUBERILLE_OK;
 }
 
+int cuberille_minimum_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above) {
+  if (!img || !prm) return CUBERILLE_ERR_ARGUMENT;
+  for (int i = 0; i < 3; i++) if (!(img->spacing[i] > 0.0)) return CUBERILLE_ERR_ARGUMENT;
+  Geo geo{};
+  Params p{};
+  resolve(img, prm, geo, p);
+  long long lo = 2, hi = 1;                      // the topology: ghost slice + the one under it; one slice above
+  if (p.project) {
+    // a vertex starts at index-space z = cz + oz, oz = -(row z of PhysicalPointToIndex) . spacing / 2 (txx:266-270: the
+    // half-spacing shift is taken per PHYSICAL axis; -1/2 for an axis-aligned image); its cell floor(cz + oz) reads
+    // slices floor - 1 .. floor + 2 (gradient ring).  Vertices that matter sit on planes own_z0 .. own_z1.
+    double oz = 0.0;
+    for (int k = 0; k < 3; k++) oz -= geo.p2i[6 + k] * (geo.spacing[k] / 2.0);
+    const long long b = 1 - (long long)std::floor(oz - 1e-6), a = (long long)std::floor(oz + 1e-6) + 3;
+    if (b > lo) lo = b;
+    if (a > hi) hi = a;
+  }
+  if (below) *below = lo;
+  if (above) *above = hi;
+  return CUBERILLE_OK;
+}
+
 int cuberille_count(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
                     const cuberille_params *prm, const cuberille_slab *slab, uint64_t *n_points, uint64_t *n_cells) {
   int rc = validate(c, img, dev_voxels, prm);
   if (rc) return rc;
   rc = count_prepare(c, img, dev_voxels, prm, slab);
   if (rc) return rc;
+  rc = classify_slab(c, img, slab);
+  if (rc) return rc;
+  return count_finish(c, n_points, n_cells);
+}
+
+}  // extern "C"
+
+namespace {
+
+// threshold the buffer of a prepared count: at once, or the owned slices now and the halo slices behind the caller's event
+int classify_slab(cuberille_ctx *c, const cuberille_image_desc *img, const cuberille_slab *slab) {
   const Grid &g = c->g;
   hipStream_t s = c->stream;
   if (slab && slab->voxels_ready_event) HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->voxels_ready_event, 0));
   if (slab && slab->halo_ready_event && (g.oz0 > 0 || g.oz1 < g.nzb)) {
     // the caller's halo exchange is still in flight: threshold the owned slices now, the halo
     // slices once the event it recorded behind the exchange has fired
-    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, g.oz0, g.oz1, c->tune, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm, g.oz0, g.oz1, c->tune, s));
     HIP_TRY(c, hipStreamWaitEvent(s, (hipEvent_t)slab->halo_ready_event, 0));
-    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, 0, g.oz0, c->tune, s));
-    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, g.oz1, g.nzb, c->tune, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm, 0, g.oz0, c->tune, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm, g.oz1, g.nzb, c->tune, s));
   } else {
-    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm.iso, 0, g.nzb, c->tune, s));
+    HIP_TRY(c, launch_classify(img->pixel_type, c->w, g, c->prm, 0, g.nzb, c->tune, s));
   }
-  return count_finish(c, n_points, n_cells);
+  return CUBERILLE_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int cuberille_recount(cuberille_ctx *c, const void *dev_source_bits, uint64_t *n_points, uint64_t *n_cells) {
   if (!c || !dev_source_bits) return CUBERILLE_ERR_ARGUMENT;
@@ -465,7 +545,10 @@ int cuberille_recount(cuberille_ctx *c, const void *dev_source_bits, uint64_t *n
   c->g.extAlias = 1;
   c->counted = false;
   c->pointsEmitted = false;                  // the counts change: whatever cuberille_emit_points started is void
+  c->pointsStartedEarly = false;
+  c->escapeChecked = false;
   HIP_TRY(c, hipMemsetAsync(c->w.totals, 0, sizeof(Totals), s));
+  HIP_TRY(c, hipEventRecord(c->ev[0], s));   // ms_pass of a recounted slab: this count alone, not the host time since the first
   return count_finish(c, n_points, n_cells);
 }
 
@@ -505,12 +588,16 @@ namespace {
 
 // The part of the emit that needs no id offsets: buffers, head tables, vertex scatter, projection.  Runs once per count
 // (cuberille_emit_points may have started it already, while the caller was gathering the counts of the other ranks).
-int emit_points_phase(cuberille_ctx *c) {
+// dyn (cuberille_step_begin): buffers and launches are sized for the cover values, the kernels read the real counts
+// from the device and run only when they fit (Totals::go).
+int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 coverQ = 0, u32 coverVW = 0) {
   if (c->pointsEmitted) return CUBERILLE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  const u64 nV = c->tot.totV;                 // ghost + owned
-  const u64 nGhost = c->tot.V0;
-  const u64 nQ = c->tot.totQ - c->tot.Q0;
+  const u64 nV = dyn ? coverV : c->tot.totV;                 // ghost + owned
+  const u64 nGhost = dyn ? 0 : c->tot.V0;
+  const u64 totQ = dyn ? coverQ : c->tot.totQ;
+  const u64 nQ = dyn ? coverQ : c->tot.totQ - c->tot.Q0;
+  const u32 nVW = dyn ? coverVW : c->tot.nVertexWords;
   // room behind this rank's points for the positions of a plane of the rank below's vertices (quirk Q1 across slabs)
   const size_t planeCorners = (c->slabMode || c->g.extAlias) ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;
   HIP_TRY(c, c->points.reserve((size_t)(nV + planeCorners ? nV + planeCorners : 1) * 3 * sizeof(float)));
@@ -529,18 +616,74 @@ int emit_points_phase(cuberille_ctx *c) {
   // head tables for the per-wave inverse mapping (4 B per 64 outputs)
   w.headV = w.headQ = nullptr;
   if (c->nwords < 0xffffffffULL && !c->tune.no_heads) {
-    if (c->headQ.reserve((size_t)(c->tot.totQ / 64 + 2) * sizeof(u32)) == hipSuccess) w.headQ = (u32 *)c->headQ.p;
+    if (c->headQ.reserve((size_t)(totQ / 64 + 2) * sizeof(u32)) == hipSuccess) w.headQ = (u32 *)c->headQ.p;
     if (!w.vqueue && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess) w.headV = (u32 *)c->headV.p;
     (void)hipGetLastError();
   }
+  // THIN_HALO: room for the vertices whose walk leaves the buffer (more than these: the step is redone with the deep halo)
+  w.escList = nullptr;
+  w.escCap = 0;
+  if (c->thinHalo) {
+    const size_t cap = nV < ESCAPE_LIST_CAP ? (size_t)nV + 1 : (size_t)ESCAPE_LIST_CAP;
+    HIP_TRY(c, c->escList.reserve(cap * sizeof(u32)));
+    w.escList = (u32 *)c->escList.p;
+    w.escCap = (u32)cap;
+  }
+  // (the blind form needs every scratch table: the fallbacks without them size their launches from the counts)
+  if (dyn && (!w.cmap || !w.headQ || !w.vqueue || c->tune.points_variant != 3))
+    return fail(c, CUBERILLE_ERR_STATE, "internal: blind launch without the scratch tables");
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  HIP_TRY(c, launch_heads(w, c->g, c->tot.totV, c->tot.totQ, s));
-  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, c->tot.nVertexWords, c->tune, s));
+  HIP_TRY(c, launch_heads(w, c->g, nV, totQ, dyn ? 1 : 0, s));
+  HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, nVW, c->tune, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
-  if (c->prm.project) HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, s));
+  if (c->prm.project)
+    HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
   c->pointsEmitted = true;
+  return CUBERILLE_OK;
+}
+
+// After the last kernel of an extraction has completed and the totals are back in pinned memory: statistics, device times.
+int finish_result(cuberille_ctx *c, cuberille_result *res) {
+  c->tot.iters = c->hostTotals->iters;
+  c->tot.stopSteps = c->hostTotals->stopSteps;
+  c->tot.stopThr = c->hostTotals->stopThr;
+  c->tot.nEscaped = c->hostTotals->nEscaped;
+  c->tot.err = c->hostTotals->err;
+  cuberille_result &r = c->res;
+  r.ms_scan = 0.0f;                          // the prefix sums are part of the count stage (k_count + k_block_scan)
+  if (c->stagesTimed) {                      // (the switch as it was when the count ran)
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->pointsStartedEarly ? c->ev[3] : c->ev[6], c->ev[7]));
+  }
+  float b = 0.f, b2 = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
+  if (c->pointsStartedEarly) {
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[6]));
+    HIP_TRY(c, hipEventElapsedTime(&b2, c->ev[3], c->ev[7]));
+  } else {
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
+  }
+  r.ms_total = r.ms_pass + b + b2;           // device time: the host's turn between count and emit is in none of the intervals
+  r.proj_iterations = c->tot.iters;
+  r.proj_stop_steps = r.proj_stop_threshold = 0;
+  if (c->prm.project) {
+    r.proj_stop_steps = c->tot.stopSteps;
+    // the default branch ends every walk one way or the other (txx:456-472): only the rare way is counted on the device
+    r.proj_stop_threshold = c->prm.variant == CUBERILLE_PROJECT_DEFAULT ? r.n_points - c->tot.stopSteps : c->tot.stopThr;
+  }
+  r.n_escaped = c->tot.nEscaped;
+  // what this extraction produced sizes the blind launches of the next cuberille_step_begin on this context
+  c->haveHistory = true;
+  c->histV = c->tot.totV; c->histQ = c->tot.totQ; c->histVW = c->tot.nVertexWords;
+  c->stepMode = 0;
+  c->haveMesh = true;
+  c->counted = false;                        // the workspace now belongs to this mesh
+  if (res) *res = r;
   return CUBERILLE_OK;
 }
 
@@ -559,12 +702,61 @@ extern "C" {
 
 int cuberille_emit_points(cuberille_ctx *c) {
   if (!c) return CUBERILLE_ERR_ARGUMENT;
-  const int rc = emit_preconditions(c, "cuberille_emit_points");
+  int rc = emit_preconditions(c, "cuberille_emit_points");
   if (rc) return rc;
-  return emit_points_phase(c);
+  if (c->pointsEmitted) return CUBERILLE_OK;
+  rc = emit_points_phase(c);
+  if (rc) return rc;
+  // the caller turns to the other ranks now: this phase gets its own end mark, cuberille_emit starts a second interval
+  if (!c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+  c->pointsStartedEarly = true;
+  return CUBERILLE_OK;
 }
 
-int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_offset, cuberille_result *res) {
+int cuberille_escaped_count(cuberille_ctx *c, uint64_t *n_escaped) {
+  if (!c || !n_escaped) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted || !c->pointsEmitted)
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_escaped_count follows cuberille_emit_points");
+  *n_escaped = 0;
+  if (!c->thinHalo) return CUBERILLE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->hostTotals, c->w.totals, sizeof(Totals), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tot.nEscaped = c->hostTotals->nEscaped;
+  c->tot.err = c->hostTotals->err;
+  c->escapeChecked = true;
+  *n_escaped = (c->tot.err & ERRF_ESCAPE_OVERFLOW) ? UINT64_MAX : (uint64_t)c->tot.nEscaped;
+  return CUBERILLE_OK;
+}
+
+int cuberille_reproject_escaped(cuberille_ctx *c, const void *dev_voxels, int64_t z_begin, int64_t nz) {
+  if (!c || !dev_voxels) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted || !c->pointsEmitted || !c->thinHalo)
+    return fail(c, CUBERILLE_ERR_STATE, "cuberille_reproject_escaped follows cuberille_emit_points on a THIN_HALO slab");
+  if (c->tot.err & ERRF_ESCAPE_OVERFLOW)
+    return fail(c, CUBERILLE_ERR_LIMIT, "more walks left the thin halo than the escape list holds: count the slab again with "
+                                        "the full halo (cuberille_required_halo)");
+  // the deeper buffer must hold what a slab without the flag would have had to
+  const long long reach = projection_reach(c->geo, c->prm);
+  const long long lo = reach > 2 ? reach : 2, hi = reach > 1 ? reach : 1;
+  const long long own0 = c->g.zglob0 + c->g.oz0, own1 = c->g.zglob0 + c->g.oz1;
+  const long long needLo = own0 >= lo ? own0 - lo : 0, needHi = own1 + hi < c->g.gnz ? own1 + hi : c->g.gnz;
+  if (nz < 1 || z_begin < 0 || z_begin + nz > c->g.gnz || z_begin > needLo || z_begin + nz < needHi)
+    return fail(c, CUBERILLE_ERR_HALO, "the deeper buffer does not hold the halo these parameters need (cuberille_required_halo)");
+  const u64 n = c->tot.nEscaped;
+  if (n == 0) return CUBERILLE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Grid deep = c->g;
+  deep.nzb = (int)nz;
+  deep.zglob0 = z_begin;
+  Workspace w = c->w;
+  w.vox = dev_voxels;
+  HIP_TRY(c, launch_project(c->pixel_type, w, deep, c->geo, c->prm, n, c->tot.V0, c->tune, 2, 0, c->stream));
+  c->tot.nEscaped = 0;
+  return CUBERILLE_OK;
+}
+
+int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result *res) {
   if (!c) return CUBERILLE_ERR_ARGUMENT;
   int rc = emit_preconditions(c, "cuberille_emit");
   if (rc) return rc;
@@ -572,41 +764,151 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, uint64_t cell_id_
   const bool needPlane = c->g.extAlias && c->aliasZ >= c->g.oz0;
   if (needPlane && (!c->extIds || !c->extPts))
     return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
-  (void)cell_id_offset;   // cells are returned per rank; their ids are positions, only point ids are global
   c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
   c->pointOffset = point_id_offset;
   rc = emit_points_phase(c);
   if (rc) return rc;
+  if (c->thinHalo) {
+    // no cell is written while a vertex waits for slices this buffer lacks (the count and the vertex phase stand: the
+    // caller fetches the deeper halo, calls cuberille_reproject_escaped and comes back)
+    uint64_t nEsc = c->tot.nEscaped;
+    if (!c->escapeChecked && (rc = cuberille_escaped_count(c, &nEsc)) != CUBERILLE_OK) return rc;
+    if (nEsc)
+      return fail(c, CUBERILLE_ERR_HALO, std::to_string(nEsc) + " walks left the thin halo: cuberille_reproject_escaped "
+                                         "with the deeper buffer comes before cuberille_emit");
+  }
   const u64 nV = c->tot.totV;
   const u64 nQ = c->tot.totQ - c->tot.Q0;
   const size_t planeCorners = needPlane ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;   // positions of the rank below's vertices
   Workspace &w = c->w;
   hipStream_t s = c->stream;
+  // the vertex phase was started ahead of this call (cuberille_emit_points): the device may have idled since, waiting
+  // for the host's all-gather -- the cell phase is timed as an interval of its own
+  if (c->pointsStartedEarly) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr, s));
+  HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr,
+                               nullptr, 0, 0, 0, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
-  c->tot.iters = c->hostTotals->iters;
-  cuberille_result &r = c->res;
-  r.ms_scan = 0.0f;                          // the scans run inside the count kernel (its last block)
-  if (c->stagesTimed) {                      // (the switch as it was when the count ran)
-    HIP_TRY(c, hipEventElapsedTime(&r.ms_classify, c->ev[0], c->ev[1]));
-    HIP_TRY(c, hipEventElapsedTime(&r.ms_count, c->ev[1], c->ev[2]));
-    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_points, c->ev[4], c->ev[5]));
-    HIP_TRY(c, hipEventElapsedTime(&r.ms_project, c->ev[5], c->ev[6]));
-    HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->ev[6], c->ev[7]));
+  return finish_result(c, res);
+}
+
+// ---- one step without a host round trip between count and emit (the multi-GPU steady state) -------------------------
+int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
+                         const cuberille_slab *slab, const void **dev_row, size_t *row_bytes) {
+  int rc = validate(c, img, dev_voxels, prm);
+  if (rc) return rc;
+  if (!dev_row || !row_bytes) return fail(c, CUBERILLE_ERR_ARGUMENT, "null row pointer");
+  rc = count_prepare(c, img, dev_voxels, prm, slab);
+  if (rc) return rc;
+  rc = classify_slab(c, img, slab);
+  if (rc) return rc;
+  // blind launches need: the sizes of a previous extraction on this context, the default projection branch and every
+  // scratch table (the vertex-word queue is set up by count_prepare; the others are checked below)
+  const bool blind = c->haveHistory && c->w.vqueue && !c->tune.no_cmap && !c->tune.no_heads && c->tune.points_variant == 3 &&
+                     (!c->prm.project || c->prm.variant == CUBERILLE_PROJECT_DEFAULT) && c->histV + c->histV / 4 < 0xfffff000ULL;
+  if (blind) {
+    Gate gate{};
+    gate.on = 1;
+    gate.coverV = c->histV + c->histV / 4 + 4096;
+    gate.coverQ = c->histQ + c->histQ / 4 + 4096;
+    const u64 vw = (u64)c->histVW + c->histVW / 4 + 1024;
+    gate.coverVW = (u32)(vw < c->nwords ? vw : c->nwords);
+    rc = count_launch(c, gate);
+    if (rc) return rc;
+    rc = emit_points_phase(c, true, gate.coverV, gate.coverQ, gate.coverVW);
+    if (rc == CUBERILLE_OK) {
+      c->stepMode = 1;
+    } else {
+      // a table could not be had: the count is in flight all the same, read it and go on by the exact sizes
+      c->pointsEmitted = false;
+      rc = totals_to_host(c);
+      if (rc) return rc;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      adopt_totals(c, nullptr, nullptr);
+      // (Totals::go was set by the gate: a count that fits it may have let nothing run, the exact launches below do not ask)
+    }
+  } else {
+    rc = count_finish(c, nullptr, nullptr);
+    if (rc) return rc;
   }
-  float b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
-  HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
-  r.ms_total = r.ms_pass + b;                // device time; excludes the host gap between count and emit
-  r.proj_iterations = c->tot.iters;
-  c->haveMesh = true;
-  c->counted = false;                        // the workspace now belongs to this mesh
-  if (res) *res = r;
+  if (c->stepMode != 1) {
+    // sized by a host read (the first extraction on a context, a fallback configuration): the vertex phase unless a
+    // quirk-Q1 flag says that the counts may still change
+    c->stepMode = 2;
+    if (!c->aliasBelowBuffer) {
+      rc = emit_points_phase(c);
+      if (rc) return rc;
+    }
+  }
+  if (c->pointsEmitted) {
+    if (!c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+    c->pointsStartedEarly = true;
+  }
+  *dev_row = c->w.totals;
+  *row_bytes = sizeof(Totals);
   return CUBERILLE_OK;
+}
+
+int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank, cuberille_result *res) {
+  if (!c || !dev_rows || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? fail(c, CUBERILLE_ERR_ARGUMENT, "bad rows or rank") : CUBERILLE_ERR_ARGUMENT;
+  if (c->stepMode == 0) return fail(c, CUBERILLE_ERR_STATE, "cuberille_step_end follows cuberille_step_begin");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const bool blind = c->stepMode == 1;
+  if (c->hostRowsCap < (size_t)n_ranks) {
+    if (c->hostRows) (void)hipHostFree(c->hostRows);
+    c->hostRows = nullptr;
+    c->hostRowsCap = 0;
+    HIP_TRY(c, hipHostMalloc((void **)&c->hostRows, (size_t)n_ranks * sizeof(Totals), hipHostMallocDefault));
+    c->hostRowsCap = (size_t)n_ranks;
+  }
+  HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  // the cells, unless a flag stands somewhere (the kernel looks at the rows itself: every rank decides alike).  Sized
+  // by the cover values (blind) or by this rank's counts; a rank whose vertex phase did not run launches nothing.
+  if (blind || c->pointsEmitted) {
+    const u64 nQ = blind ? c->histQ + c->histQ / 4 + 4096 : c->tot.totQ - c->tot.Q0;
+    HIP_TRY(c, launch_emit_cells(c->w, c->g, c->prm.triangles, c->prm.q1, 0, nQ, nullptr, (const Totals *)dev_rows, n_ranks, rank,
+                                 blind ? 1 : 0, s));
+  }
+  HIP_TRY(c, hipEventRecord(c->ev[7], s));
+  {
+    const int rc = totals_to_host(c);
+    if (rc) return rc;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->hostRows, dev_rows, (size_t)n_ranks * sizeof(Totals), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));                  // the one wait of the step
+  u32 flags = 0;
+  u64 off = 0;
+  for (int r = 0; r < n_ranks; r++) {
+    flags |= c->hostRows[r].err;
+    if (r < rank) off += c->hostRows[r].totV - c->hostRows[r].V0;
+  }
+  const u32 mine = c->hostTotals->err;
+  if (blind) {
+    const bool ran = c->hostTotals->go != 0;
+    adopt_totals(c, nullptr, nullptr);
+    c->pointsEmitted = ran;                             // (a gate that said no: nothing ran, nothing is valid)
+    if (!ran) c->pointsStartedEarly = false;
+  } else {
+    c->tot.nEscaped = c->hostTotals->nEscaped;
+    c->tot.err = c->hostTotals->err;
+  }
+  c->escapeChecked = c->pointsEmitted;
+  c->stepMode = 0;
+  if (flags) {
+    // nothing was written; the count stands and the synchronous calls take over from it (slab_info, recount,
+    // emit_points, escaped_count / reproject_escaped, emit)
+    (void)mine;
+    c->err = "cuberille_step_end: a flag stands on some rank (quirk Q1 across slabs, capacity, or a walk left a thin halo)";
+    if (res) *res = c->res;                             // the counts (what cuberille_count would have returned)
+    return CUBERILLE_RETRY;
+  }
+  c->slabMesh = off != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
+  c->pointOffset = off;
+  return finish_result(c, res);
 }
 
 int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
@@ -614,12 +916,33 @@ int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, 
   uint64_t np = 0, nc = 0;
   int rc = cuberille_count(c, img, dev_voxels, prm, slab, &np, &nc);
   if (rc) return rc;
-  return cuberille_emit(c, slab ? slab->point_id_offset : 0, slab ? slab->cell_id_offset : 0, res);
+  return cuberille_emit(c, slab ? slab->point_id_offset : 0, res);
 }
 
 }  // extern "C"
 
 namespace {
+
+// The pinned staging ring of the chunked copies (two slots of `bytes`, their events, the copy stream), (re)made in one
+// place: the recorded size only ever describes two live slots.
+int ensure_staging(cuberille_ctx *c, size_t bytes) {
+  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
+    if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
+  }
+  if (c->stageBytes >= bytes && c->stage[0] && c->stage[1]) return CUBERILLE_OK;
+  c->stageBytes = 0;
+  for (int i = 0; i < 2; i++)
+    if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+  for (int i = 0; i < 2; i++) {
+    if (g_fail_alloc_countdown >= 0 && g_fail_alloc_countdown-- == 0)
+      return fail(c, CUBERILLE_ERR_HIP, "hipHostMalloc(staging slot): out of memory (failure drill)");
+    HIP_TRY(c, hipHostMalloc(&c->stage[i], bytes, hipHostMallocDefault));
+  }
+  c->stageBytes = bytes;
+  return CUBERILLE_OK;
+}
 
 // Host threads that copy pageable caller memory into the pinned staging ring, one fixed share of every chunk
 // each (a single memcpy stream cannot feed a PCIe Gen5 link; a handful can).
@@ -654,16 +977,8 @@ int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, co
   }
   // large volumes: z-chunks through a pinned double buffer on a copy stream; chunk i is thresholded on the
   // context's stream while chunk i+1 crosses the link and the host threads stage chunk i+2
-  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
-  if (c->stageBytes < kChunk) {
-    for (int i = 0; i < 2; i++) {
-      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
-      HIP_TRY(c, hipHostMalloc(&c->stage[i], kChunk, hipHostMallocDefault));
-      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
-      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
-    }
-    c->stageBytes = kChunk;
-  }
+  rc = ensure_staging(c, kChunk);
+  if (rc) return rc;
   rc = count_prepare(c, img, c->voxOwn.p, prm, nullptr);
   if (rc) return rc;
   const size_t slicesPerChunk = kChunk / sliceBytes;
@@ -701,7 +1016,7 @@ int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, co
                        c->copyStream);
     if (e == hipSuccess) e = hipEventRecord(c->chunkIn[i & 1], c->copyStream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->chunkIn[i & 1], 0);
-    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm.iso, (int)z0, (int)z1, c->tune, c->stream);
+    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm, (int)z0, (int)z1, c->tune, c->stream);
     // slot (i & 1) is free for chunk i + 2 once this chunk has crossed the link
     if (e == hipSuccess && i + 2 < nchunks) {
       e = hipEventSynchronize(c->chunkIn[i & 1]);
@@ -714,7 +1029,7 @@ int cuberille_extract_host(cuberille_ctx *c, const cuberille_image_desc *img, co
   uint64_t np = 0, nc = 0;
   rc = count_finish(c, &np, &nc);
   if (rc) return rc;
-  return cuberille_emit(c, 0, 0, res);
+  return cuberille_emit(c, 0, res);
 }
 
 int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, cuberille_chunk_source source, void *user,
@@ -731,17 +1046,8 @@ int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, 
   const size_t slicesPerChunk = sliceBytes >= (32u << 20) ? 1 : (32u << 20) / sliceBytes;
   const size_t chunkBytes = slicesPerChunk * sliceBytes;
   const size_t nchunks = (nz + slicesPerChunk - 1) / slicesPerChunk;
-  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
-  if (c->stageBytes < chunkBytes) {
-    for (int i = 0; i < 2; i++) {
-      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
-      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
-      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
-    }
-    c->stageBytes = 0;
-    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->stage[i], chunkBytes, hipHostMallocDefault));
-    c->stageBytes = chunkBytes;
-  }
+  rc = ensure_staging(c, chunkBytes);
+  if (rc) return rc;
   rc = count_prepare(c, img, c->voxOwn.p, prm, nullptr);
   if (rc) return rc;
   hipError_t e = hipSuccess;
@@ -757,7 +1063,7 @@ int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, 
                        c->copyStream);
     if (e == hipSuccess) e = hipEventRecord(c->chunkIn[i & 1], c->copyStream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->chunkIn[i & 1], 0);
-    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm.iso, (int)z0, (int)z1, c->tune, c->stream);
+    if (e == hipSuccess) e = launch_classify(img->pixel_type, c->w, c->g, c->prm, (int)z0, (int)z1, c->tune, c->stream);
   }
   if (gaveUp || e != hipSuccess) {
     // let what is in flight finish before the staging slots are used again
@@ -769,7 +1075,7 @@ int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, 
   uint64_t np = 0, nc = 0;
   rc = count_finish(c, &np, &nc);
   if (rc) return rc;
-  return cuberille_emit(c, 0, 0, res);
+  return cuberille_emit(c, 0, res);
 }
 
 int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
@@ -856,16 +1162,9 @@ int download_pipelined(cuberille_ctx *c, void *dst, const void *src, size_t byte
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CUBERILLE_OK;
   }
-  if (!c->copyStream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
-  if (c->stageBytes < kChunk) {
-    for (int i = 0; i < 2; i++) {
-      if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
-      if (!c->stageFree[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stageFree[i], hipEventDisableTiming));
-      if (!c->chunkIn[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->chunkIn[i], hipEventDisableTiming));
-    }
-    c->stageBytes = 0;
-    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->stage[i], kChunk, hipHostMallocDefault));
-    c->stageBytes = kChunk;
+  {
+    const int rc = ensure_staging(c, kChunk);
+    if (rc) return rc;
   }
   // the mesh was written on the context's stream
   HIP_TRY(c, hipEventRecord(c->stageFree[0], c->stream));

@@ -48,16 +48,23 @@ struct Totals {        // device-resident, zeroed before every count, mirrored t
   u64 g0pre;           // in-block prefix (V | Q << 32) at the first owned word, left by the count block that holds it
   u32 err;             // device-side error flags
   u32 nVertexWords;    // entries in the vertex-word queue (words that create at least one vertex)
-  u32 pad_[2];
+  u32 nEscaped;        // THIN_HALO slabs: vertices whose walk asked for a slice the buffer lacks (entries of the escape list,
+                       // or more than it holds: ERRF_ESCAPE_OVERFLOW)
+  u32 go;              // cuberille_step_begin: 1 when the kernels launched blindly behind the count may run (k_gate)
+  u64 stopThr, stopSteps;   // walks of owned vertices that ended within the threshold / out of steps (txx:457-459, 470-472)
 };
 
 enum {
   ERRF_ALIAS_UNKNOWN = 1,        // quirk Q1: the aliased source slice is in the buffer but below the counted range
-  ERRF_ALIAS_BELOW_BUFFER = 2    // quirk Q1: the search for the source slice ran off the bottom of a slab buffer
+  ERRF_ALIAS_BELOW_BUFFER = 2,   // quirk Q1: the search for the source slice ran off the bottom of a slab buffer
+  ERRF_CAPACITY = 4,             // cuberille_step_begin: the counts exceed what the blind launches / buffers were sized for
+  ERRF_ESCAPE = 8,               // THIN_HALO: at least one walk left the buffer (Totals::nEscaped)
+  ERRF_ESCAPE_OVERFLOW = 16      // ... and more of them than the escape list holds
 };
 
 // A count block owns COUNT_WB consecutive words of the flat raster order = 32 scan segments of 64 words.
 // Absolute exclusive prefix of word gi = blockBase[gi >> COUNT_LG] + segPre[gi >> 6] + prefix[gi].
+constexpr unsigned ESCAPE_LIST_CAP = 1u << 20;   // entries of the THIN_HALO escape list (4 MiB)
 constexpr int COUNT_LG = 11;
 constexpr int COUNT_WB = 1 << COUNT_LG;
 
@@ -76,6 +83,8 @@ struct Workspace {     // device pointers valid for one count/emit pair
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
   u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
   u32 *vqueue;         // counted-range indices of the words that create vertices, in no particular order (or null)
+  u32 *escList;        // THIN_HALO: indices (in this rank's point buffer) of the vertices whose walk left the buffer
+  u32 escCap;
 };
 
 // Development switches, set per context through cuberille_debug_set_option (never read from the environment).
@@ -91,26 +100,35 @@ struct Tuning {
 
 struct Params {
   double iso;
+  long long isoInt;           // the iso value of the 64-bit integer pixel types (a double cannot hold it past 2^53)
   double thr, step, relax;
   u32 max_steps;
   int triangles, project, q1;
   int variant;                // CUBERILLE_PROJECT_*
 };
 
-// launchers (cuberille_kernels.hip); all asynchronous on `s`
-hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, double iso, int z0, int z1, const Tuning &t,
+// cuberille_step_begin: what the launches behind the count were sized for (k_block_scan sets Totals::go accordingly)
+struct Gate {
+  int on;
+  u64 coverV, coverQ;
+  u32 coverVW;
+};
+
+// launchers (cuberille_kernels.hip); all asynchronous on `s`.  dyn: the launch is sized for an estimate, the kernel
+// reads the real sizes from the device totals and runs only when Totals::go says so.
+hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, const Params &p, int z0, int z1, const Tuning &t,
                            hipStream_t s);
 hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s);
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, hipStream_t s);
-hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, hipStream_t s);
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, hipStream_t s);
+hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, int dyn, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
-                              const Tuning &t, hipStream_t s);
+                              const Tuning &t, int dyn, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
-                             const u64 *extIds, hipStream_t s);
+                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s);
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
                               hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
-                          const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, hipStream_t s);
+                          const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, int mode, int dyn, hipStream_t s);
 
 }  // namespace cuberille
 #endif

@@ -42,6 +42,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __device__ __forceinline__ u64 lowmask(int b) { return (1ull << b) - 1ull; }   // b in 0..63
 __device__ __forceinline__ int popc64(u64 v) { return __popcll(v); }
 
+// the iso value in the pixel type (txx:140: m_IsoSurfaceValue IS an InputPixelType): a C cast of the double, except for
+// the 64-bit integer types, whose value travels as an integer
+template <class T>
+__device__ __forceinline__ T iso_as(double isoD, long long isoI) {
+  if constexpr (std::is_integral<T>::value && sizeof(T) == 8) return (T)isoI;
+  else return (T)isoD;
+}
+
 // corner number i (txx:244-251) -> block position code e = x | y<<1 | z<<2, and back
 __device__ __constant__ const int kCornerEnc[8] = {0, 1, 3, 2, 4, 5, 7, 6};
 __device__ __constant__ const int kEncCorner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
@@ -94,11 +102,11 @@ __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
 // words together.  One wave turns U KiB of voxels into U*VPL words per trip.
 template <class T, int U, bool NT>
 __global__ __launch_bounds__(256) void k_classify_flat(const T *__restrict__ vox, u64 *__restrict__ bits,
-                                                       u64 nchunks, double isoD, u32 *__restrict__ sliceOcc,
+                                                       u64 nchunks, double isoD, long long isoI, u32 *__restrict__ sliceOcc,
                                                        int lgWordsPerSlice, u64 wordBase) {
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
-  const T iso = (T)isoD;
+  const T iso = iso_as<T>(isoD, isoI);
   const int lane = threadIdx.x & 63;
   const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -164,14 +172,15 @@ constexpr int SPAN_WORDS = 4096;
 
 template <class T>
 __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
-                                                       double isoD, u32 *__restrict__ sliceOcc, int lgWordsPerSlice) {
+                                                       double isoD, long long isoI, u32 *__restrict__ sliceOcc,
+                                                       int lgWordsPerSlice) {
   constexpr int U = 4;
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
   constexpr int TRIPS = SPAN_WORDS / (4 * U * VPL);      // trips of U KiB per wave and span
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) u64 stage[SPAN_WORDS];
-  const T iso = (T)isoD;
+  const T iso = iso_as<T>(isoD, isoI);
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane % LPW;
@@ -217,10 +226,10 @@ __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox
 // finishes the last, partial 1 KiB chunk ...
 template <class T>
 __global__ __launch_bounds__(64) void k_classify_tail(const T *__restrict__ abase, u64 *__restrict__ flat, u64 firstVec,
-                                                      u64 nvec, double isoD) {
+                                                      u64 nvec, double isoD, long long isoI) {
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
-  const T iso = (T)isoD;
+  const T iso = iso_as<T>(isoD, isoI);
   const int lane = threadIdx.x & 63;
   const u64 v = firstVec + lane;
   u32 m = 0;
@@ -261,8 +270,8 @@ __global__ __launch_bounds__(256) void k_repack_rows(const u64 *__restrict__ fla
 template <class T>
 __global__ __launch_bounds__(256) void k_classify_rows(const T *__restrict__ vox, u64 *__restrict__ bits,
                                                        int nx, int W, u64 t0, u64 nrows, u64 rowsPerSlice, double isoD,
-                                                       u32 *__restrict__ sliceOcc) {
-  const T iso = (T)isoD;
+                                                       long long isoI, u32 *__restrict__ sliceOcc) {
+  const T iso = iso_as<T>(isoD, isoI);
   const int lane = threadIdx.x & 63;
   const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -723,8 +732,10 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
 // workgroup: rows of 1024 consecutive blocks, coalesced loads, ROWS rows in flight at once (the loads are what
 // takes time), then per row a workgroup-wide exclusive scan; V and Q of a row fit 32 bits each (1024 x 2^21),
 // the running bases are 64-bit.
+// gate (cuberille_step_begin): the launches behind this one were sized from the previous extraction; they only run
+// (Totals::go) when the counts fit what they were sized for and no flag of the count stands.
 __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blockTot, u64 *__restrict__ blockBase, u32 nblk,
-                                                     size_t g0, Totals *__restrict__ tot) {
+                                                     size_t g0, Totals *__restrict__ tot, Gate gate) {
   constexpr int ROWS = 8;
   __shared__ u64 waveSum[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -762,7 +773,16 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
       __syncthreads();
     }
   }
-  if (tid == 0) { tot->totV = runV; tot->totQ = runQ; }
+  if (tid == 0) {
+    tot->totV = runV;
+    tot->totQ = runQ;
+    if (gate.on) {
+      u32 err = tot->err;
+      if (runV > gate.coverV || runQ > gate.coverQ || tot->nVertexWords > gate.coverVW) err |= (u32)ERRF_CAPACITY;
+      tot->err = err;
+      tot->go = (err & (u32)(ERRF_ALIAS_UNKNOWN | ERRF_ALIAS_BELOW_BUFFER | ERRF_CAPACITY)) == 0 ? 1u : 0u;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -784,6 +804,9 @@ struct EmitArgs {
   const u32 *headV, *headQ;   // word producing output 64*i (k_heads_search), or null
   const u64 *extIds;   // Grid::extAlias: global ids of the top-plane corners of the source slice, dense (nx+1) x (ny+1);
                        // their positions stand behind this rank's own points, from index totV on
+  const Totals *rows;  // cuberille_step_end: the gathered totals of all ranks (device memory), or null
+  int nRanks, rank;    //   -> this rank's point id offset = owned points of the ranks below; any flag on any rank: no cells
+  int dyn;             // the launch was sized blindly (cuberille_step_begin): sizes from `tot`, and only when tot->go
 };
 
 // absolute exclusive prefix (SHIFT 0: vertices, 16: quads) at the start of the segment that holds word gi
@@ -819,6 +842,12 @@ __device__ __forceinline__ void corner_point(const Geo &geo, long long cx, long 
     const float v = (float)(sum + geo.origin[r]);
     p[r] = (float)((double)v - (geo.spacing[r] / 2.0));
   }
+}
+
+// ... and a vertex on the BOTTOM plane of a slab's ghost slice gets a NaN x: it belongs to the rank below, no cell of
+// this rank touches that plane, and the projection skips it (it would need one more halo slice than anything else)
+__device__ __forceinline__ void ghost_bottom_mark(const Grid &g, int cz, float p[3]) {
+  if (cz == g.cz0 && g.cz0 < g.oz0) p[0] = __builtin_nanf("");
 }
 
 // Global id of lattice corner (cx,cy,cz) (cz local) by the closed form: creator = first block
@@ -906,6 +935,10 @@ __device__ __forceinline__ size_t locate_word(const EmitArgs &a, size_t nwords, 
 template <int SHIFT>
 __global__ __launch_bounds__(256) void k_heads_search(EmitArgs a, size_t nwords, u64 nHeads, u32 *__restrict__ head) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.dyn) {
+    if (!a.tot->go) return;
+    nHeads = ((SHIFT ? a.tot->totQ : a.tot->totV) + 63) / 64;
+  }
   if (t >= nHeads) return;
   u32 within;
   head[t] = (u32)locate_word<SHIFT>(a, nwords, t * 64, within);
@@ -983,6 +1016,7 @@ __global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Ge
   const int cx = k * 64 + lo + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
   float p[3];
   corner_point(geo, cx, cy, g.zglob0 + cz, p);
+  ghost_bottom_mark(g, cz, p);
   float *dst = a.points + 3 * v;                 // ghost points first, owned points from 3*V0 on
   dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
   if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
@@ -1005,6 +1039,10 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
   __shared__ u64 wv0[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.dyn) {
+    if (!a.tot->go) return;
+    nVertexWords = a.tot->nVertexWords;
+  }
   if (t - lane >= nVertexWords) return;          // wave-uniform
   const bool valid = t < nVertexWords;
   WordInfo w;
@@ -1047,6 +1085,7 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
           const int cx = k * 64 + bx + (e & 1), cy = y + ((e >> 1) & 1), cz = z + (e >> 2);
           float p[3];
           corner_point(geo, cx, cy, g.zglob0 + cz, p);
+          ghost_bottom_mark(g, cz, p);
           float *dst = a.points + 3 * v;
           dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
           if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
@@ -1067,6 +1106,7 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
     const int cx = wk[wv][src] * 64 + bx + (e & 1), cy = wy[wv][src] + ((e >> 1) & 1), cz = wz[wv][src] + (e >> 2);
     float p[3];
     corner_point(geo, cx, cy, g.zglob0 + cz, p);
+    ghost_bottom_mark(g, cz, p);
     float *dst = a.points + 3 * v;
     dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
     if (a.cmap) a.cmap[corner_map_index(g, cx, cy, cz)] = (u32)v;
@@ -1200,7 +1240,22 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 waveFirst = q - lane;
+  if (a.dyn) {
+    if (!a.tot->go) return;
+    nQ = a.tot->totQ - a.tot->Q0;
+  }
   if (waveFirst >= nQ) return;                   // wave-uniform
+  if (a.rows) {
+    // the id offset from the gathered totals of the ranks below; a flag anywhere and the step is taken again by the host
+    u32 flags = 0;
+    u64 off = 0;
+    for (int r = 0; r < a.nRanks; r++) {
+      flags |= a.rows[r].err;
+      if (r < a.rank) off += a.rows[r].totV - a.rows[r].V0;
+    }
+    if (flags) return;
+    a.pointOffset = off;
+  }
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
   int x, y, z, f;
   if (locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f)) {
@@ -1455,11 +1510,22 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // registers and only re-gathered when the walk enters another cell (steps are <= a quarter voxel
 // and shrink): the per-iteration work is then the trilinear weights, 32 multiply-adds, one sqrt
 // and three divides, all in f64 in the reference's operation order.
-template <class T>
+// MODE 0: every slice a walk can reach is in the buffer.  MODE 1 (THIN_HALO slab): a walk that enters a cell whose
+// slices (gradient ring included) the buffer lacks although the volume has them is not clamped: the vertex goes on
+// the escape list untouched and is walked again from its start once the deeper halo is there (MODE 2: the vertices
+// are taken from that list; `g` then describes the deeper buffer).  dyn (cuberille_step_begin): the launch was sized
+// blindly, the real counts are read from `tot`.
+template <class T, int MODE>
 __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
-                                                 int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot) {
+                                                 int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
+                                                 u32 *__restrict__ escList, u32 escCap, int dyn) {
   const int lane = threadIdx.x & 63;
+  if (dyn) {
+    if (!tot->go) return;
+    nPoints = tot->totV;
+    nGhost = tot->V0;
+  }
   // blocks are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2): give
   // every XCD one contiguous eighth of the vertex list so that chunks whose cells overlap (adjacent
   // rows and slices) meet in the same L2.  Placement only affects speed, never results.
@@ -1481,8 +1547,10 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   const u64 end = ((nBatches - wave + NW - 1) / NW) << lgChunk;
   Sampler<T> s{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
   const int n[3] = {g.nx, g.ny, (int)g.gnz};
-  const double iso = (double)(T)prm.iso;
+  const double iso = (double)iso_as<T>(prm.iso, prm.isoInt);
   unsigned myIters = 0;
+  u32 stopStepsW = 0;                              // wave-uniform: owned walks of this wave that ran out of steps
+  bool escapedW = false;                           // wave-uniform: some walk of this wave left the buffer (MODE 1)
   bool active = false;
   u64 idx = 0;
   float vertex[3] = {0.f, 0.f, 0.f};
@@ -1504,12 +1572,14 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         const u64 pos = next + rank;
         const u64 cand = ((wave + (pos >> lgChunk) * NW) << lgChunk) + (pos & (chunk - 1));
         if (rank < remaining && cand < nPoints) {
-          idx = cand;
+          idx = MODE == 2 ? (u64)escList[cand] : cand;
           vertex[0] = points[3 * idx]; vertex[1] = points[3 * idx + 1]; vertex[2] = points[3 * idx + 2];
           step = prm.step;
           numberOfSteps = 0;
           kc[0] = -2;
-          active = true;
+          // (a ghost vertex on the ghost slice's BOTTOM plane was written as NaN by the point pass: no cell of this
+          //  rank touches that plane, its position is the rank below's business)
+          active = !(idx < nGhost && vertex[0] != vertex[0]);
         }
       }
       const u64 take = (u64)__popcll(idle);
@@ -1521,6 +1591,20 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
       make_cell(geo, unitP2I, n, p, c);
+      bool escaped = false;
+      if (MODE == 1 && (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2])) {
+        // global slices the cell and its gradient ring read, against the buffer
+        const int zlo = max(c.lo[2] - 1, 0), zhi = min(c.hi[2] + 1, n[2] - 1);
+        escaped = zlo < s.zglob0 || zhi > s.zglob0 + s.nzb - 1;
+        if (escaped) {
+          const u32 slot = atomicAdd(&tot->nEscaped, 1u);
+          if (slot < escCap && idx <= 0xffffffffull) escList[slot] = (u32)idx;
+          else atomicOr(&tot->err, (u32)ERRF_ESCAPE_OVERFLOW);
+          active = false;                            // the point keeps its start position
+        }
+        escapedW = escapedW || __ballot(escaped) != 0ull;
+      }
+      if (!escaped) {
       if (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2]) {
         gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
 #pragma unroll
@@ -1630,11 +1714,14 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
         step *= prm.relax;                                                    // txx:468
         done = numberOfSteps++ > prm.max_steps;                               // txx:469
+        // (txx:470-472's counter; a scalar per wave -- the walks that end within the threshold are the rest)
+        stopStepsW += (u32)__popcll(__ballot(done && idx >= nGhost));
       }
       if (done) {
         points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
         if (idx >= nGhost) myIters += passes;          // the iteration statistic counts owned vertices only
         active = false;
+      }
       }
     }
   }
@@ -1643,6 +1730,8 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
   if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
+  if (lane == 0 && stopStepsW) atomicAdd(&tot->stopSteps, (u64)stopStepsW);
+  if (MODE == 1 && lane == 0 && escapedW) atomicOr(&tot->err, (u32)ERRF_ESCAPE);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1718,7 +1807,9 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
   const int lane = threadIdx.x & 63;
   const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned passes = 0;
-  if (idx < nPoints) {
+  bool byThr = false, bySteps = false;
+  // (a ghost vertex on the ghost slice's bottom plane is NaN and nobody's business here: see k_project)
+  if (idx < nPoints && !(idx < nGhost && points[3 * idx] != points[3 * idx])) {
     VariantCtx<T> x;
     x.s = Sampler<T>{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
     x.geo = geo;
@@ -1726,7 +1817,7 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
     x.unitP2I = true;
     for (int i = 0; i < 9; i++) x.unitP2I = x.unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
     x.n[0] = g.nx; x.n[1] = g.ny; x.n[2] = (int)g.gnz;
-    x.iso = (double)(T)prm.iso;
+    x.iso = (double)iso_as<T>(prm.iso, prm.isoInt);
     float vertex[3] = {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
     float normal[3];
     if (prm.variant == CUBERILLE_PROJECT_ADVANCED) {
@@ -1750,8 +1841,8 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
         swaps += (unsigned)(previousi != i);                                      // txx:374
 #pragma unroll
         for (int k = 0; k < 3; k++) vertex[k] = i ? temp[1][k] : temp[0][k];      // txx:375
-        if ((i ? d1 : d0) < prm.thr) break;                                       // txx:378-382
-        if (numberOfSteps++ > prm.max_steps) break;                               // txx:385-389
+        if ((i ? d1 : d0) < prm.thr) { byThr = true; break; }                     // txx:378-382
+        if (numberOfSteps++ > prm.max_steps) { bySteps = true; break; }           // txx:385-389
         if (swaps >= 5) break;                                                    // txx:392-396
       }
     } else {
@@ -1779,12 +1870,15 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
       for (int k = 0; k < 3; k++) vertex[k] = best[k];                            // txx:437
     }
     points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
-    if (idx < nGhost) passes = 0;                  // the iteration statistic counts owned vertices only
+    if (idx < nGhost) { passes = 0; byThr = bySteps = false; }   // the statistics count owned vertices only
   }
   unsigned sum = passes;
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
   if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
+  const u64 nThr = __ballot(byThr), nSteps = __ballot(bySteps);
+  if (lane == 0 && nThr) atomicAdd(&tot->stopThr, (u64)__popcll(nThr));
+  if (lane == 0 && nSteps) atomicAdd(&tot->stopSteps, (u64)__popcll(nSteps));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1801,6 +1895,8 @@ static hipError_t by_pixel_type(int pt, F &&fn) {
     case CUBERILLE_PIX_I32: return fn((const int32_t *)nullptr);
     case CUBERILLE_PIX_F32: return fn((const float *)nullptr);
     case CUBERILLE_PIX_F64: return fn((const double *)nullptr);
+    case CUBERILLE_PIX_I64: return fn((const int64_t *)nullptr);
+    case CUBERILLE_PIX_U64: return fn((const uint64_t *)nullptr);
   }
   return hipErrorInvalidValue;
 }
@@ -1823,9 +1919,11 @@ static int occupancy_shift(const Grid &g) {
 }
 
 // classify slices [z0, z1) of the buffer (a z-range is a contiguous range of voxels and of words)
-hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, double iso, int z0, int z1, const Tuning &tn,
-                           hipStream_t s) {
+hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, const Params &prm, int z0, int z1,
+                           const Tuning &tn, hipStream_t s) {
   if (z1 <= z0) return hipSuccess;
+  const double iso = prm.iso;
+  const long long isoI = prm.isoInt;
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     Workspace w = wAll;
@@ -1845,7 +1943,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
         const u64 nspans = nwordsAll / SPAN_WORDS;
         const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU
         const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
-        hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, w.sliceOcc, lg);
+        hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
         spanWords = nspans * SPAN_WORDS;
       }
       const u64 restWords = nwordsAll - spanWords;
@@ -1854,11 +1952,11 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
         // 256 CUs x 8 blocks of 256 threads; grid-stride over the rest; 8 KiB per wave trip, nontemporal
         const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, tn.classify_grid > 0 ? tn.classify_grid : 2048);
         hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, vox + spanWords * 64, w.bits + spanWords,
-                           nchunks, iso, w.sliceOcc, lg, spanWords);
+                           nchunks, iso, isoI, w.sliceOcc, lg, spanWords);
       }
       if (spanWords + nchunks * VPL < nwordsAll)
         hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, spanWords + nchunks * VPL, nrows,
-                           (u64)g.ny, iso, w.sliceOcc);
+                           (u64)g.ny, iso, isoI, w.sliceOcc);
     } else if (wAll.flatBits && ((uintptr_t)vox % sizeof(T)) == 0 && !tn.no_stream_classify) {
       // ragged rows: flat stream of aligned 16-byte vectors (the first and last vector may reach up to 15 bytes
       // outside the range -- same 16-byte granule as valid voxels, so the loads cannot fault, and those bits
@@ -1874,16 +1972,16 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
         // (the 32-KiB-in-flight geometry of the span kernel does not carry over: this loop waits for all its loads before
         //  it computes, 0.74 ms at U4 x 1024 workgroups vs 0.745 at U8 x 2048 on 1000^3 f32)
         const unsigned blocks = grid_for((nchunks + 7) / 8 * 64, 256, 2048);
-        hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, abase, flat, nchunks, iso,
+        hipLaunchKernelGGL((k_classify_flat<T, 8, true>), dim3(blocks), dim3(256), 0, s, abase, flat, nchunks, iso, isoI,
                            (u32 *)nullptr, -1, (u64)0);
       }
-      if (nvec % 64) hipLaunchKernelGGL((k_classify_tail<T>), dim3(1), dim3(64), 0, s, abase, flat, nchunks * 64, nvec, iso);
+      if (nvec % 64) hipLaunchKernelGGL((k_classify_tail<T>), dim3(1), dim3(64), 0, s, abase, flat, nchunks * 64, nvec, iso, isoI);
       hipLaunchKernelGGL(k_repack_rows, dim3(grid_for(nrows * g.W, 256, 0)), dim3(256), 0, s, flat, w.bits, g.nx, g.W, nrows, skew);
     } else {
       const u64 total = nrows * g.W;
       const unsigned blocks = grid_for(total * 64, 256, 8192);
       hipLaunchKernelGGL((k_classify_rows<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, g.nx, g.W, (u64)0, nrows,
-                         (u64)g.ny, iso, w.sliceOcc);
+                         (u64)g.ny, iso, isoI, w.sliceOcc);
     }
     return hipGetLastError();
   });
@@ -1896,12 +1994,12 @@ hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, hipStream_t s) {
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   hipLaunchKernelGGL(k_count<0>, dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot,
                      nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
-  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals);
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate);
   return hipGetLastError();
 }
 
@@ -1917,13 +2015,15 @@ static EmitArgs emit_args(const Workspace &w, const Grid &g, int q1, u64 pointOf
   a.cmap = w.cmap;
   a.headV = w.headV; a.headQ = w.headQ;
   a.extIds = nullptr;
+  a.rows = nullptr; a.nRanks = 0; a.rank = 0; a.dyn = 0;
   return a;
 }
 
-hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, hipStream_t s) {
+hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, int dyn, hipStream_t s) {
   if (!w.headQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const EmitArgs a = emit_args(w, g, 0, 0);
+  EmitArgs a = emit_args(w, g, 0, 0);
+  a.dyn = dyn;
   const u64 nHQ = (totQ + 63) / 64, nHV = w.headV ? (totV + 63) / 64 : 0;
   if (nHQ) hipLaunchKernelGGL((k_heads_search<16>), dim3(grid_for(nHQ, 256, 0)), dim3(256), 0, s, a, nwords, nHQ, w.headQ);
   if (nHV) hipLaunchKernelGGL((k_heads_search<0>), dim3(grid_for(nHV, 256, 0)), dim3(256), 0, s, a, nwords, nHV, w.headV);
@@ -1931,10 +2031,11 @@ hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, h
 }
 
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
-                              const Tuning &tn, hipStream_t s) {
+                              const Tuning &tn, int dyn, hipStream_t s) {
   if (!nV) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
-  const EmitArgs a = emit_args(w, g, q1, 0);
+  EmitArgs a = emit_args(w, g, q1, 0);
+  a.dyn = dyn;                                   // (only the queue form below is ever launched blindly)
   if (w.vqueue && nwords < 0xffffffffULL && tn.points_variant == 3)
     hipLaunchKernelGGL(k_emit_points_dense, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
   else
@@ -1976,11 +2077,12 @@ hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64
 }
 
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
-                             const u64 *extIds, hipStream_t s) {
+                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s) {
   if (!nQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   EmitArgs a = emit_args(w, g, q1, pointOffset);
   a.extIds = extIds;
+  a.rows = rows; a.nRanks = nRanks; a.rank = rank; a.dyn = dyn;
   const dim3 grid(grid_for(nQ, 256, 0)), block(256);
   if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nwords, nQ);
   else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nwords, nQ);
@@ -1989,8 +2091,11 @@ hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, i
   return hipGetLastError();
 }
 
+// mode: 0 plain, 1 THIN_HALO escape detection (w.escList), 2 the escaped vertices again (nPoints = their number; `g`
+// and w.vox describe the deeper buffer).  dyn: sizes from the device totals (cuberille_step_begin); nPoints is then
+// only what the launch is sized for.
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const Params &p, u64 nPoints,
-                          u64 nGhost, const Tuning &tn, hipStream_t s) {
+                          u64 nGhost, const Tuning &tn, int mode, int dyn, hipStream_t s) {
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
@@ -2013,8 +2118,14 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     // (giving each XCD a contiguous eighth of the vertex list was measured 1.6x slower: proj_xcd stays a switch)
-    hipLaunchKernelGGL((k_project<T>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points,
-                       nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals);
+#define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
+    hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
+                       w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,  \
+                       w.escCap, dyn)
+    if (mode == 1) CUBERILLE_LAUNCH_PROJECT(1);
+    else if (mode == 2) CUBERILLE_LAUNCH_PROJECT(2);
+    else CUBERILLE_LAUNCH_PROJECT(0);
+#undef CUBERILLE_LAUNCH_PROJECT
     return hipGetLastError();
   });
 }

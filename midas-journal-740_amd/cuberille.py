@@ -21,6 +21,7 @@ from .mha import Volume
 PIXEL_CODES = {
     np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
     np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6, np.dtype(np.float64): 7,
+    np.dtype(np.int64): 8, np.dtype(np.uint64): 9,
 }
 PIXEL_DTYPES = {code: dt for dt, code in PIXEL_CODES.items()}
 
@@ -38,8 +39,8 @@ def _np_dtype_of(t):
     torch = _torch()
     if _TORCH_TO_NP is None:
         _TORCH_TO_NP = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32,
-                        torch.float32: np.float32, torch.float64: np.float64}
-        for name, npd in (("uint16", np.uint16), ("uint32", np.uint32)):
+                        torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64}
+        for name, npd in (("uint16", np.uint16), ("uint32", np.uint32), ("uint64", np.uint64)):
             if hasattr(torch, name):
                 _TORCH_TO_NP[getattr(torch, name)] = npd
     return np.dtype(_TORCH_TO_NP[t.dtype])
@@ -80,8 +81,16 @@ def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, rel
                 variant=PROJECT_DEFAULT):
     """variant picks the branch of ProjectVertexToIsoSurface: the shipped one (txx:439-474) or one of the two the
     reference compiles out (USE_ADVANCED_PROJECTION txx:340-397, USE_LINESEARCH_PROJECTION txx:398-437; h:22-23)."""
+    # (the 64-bit integer pixel types take the iso value as an integer: a double cannot hold it past 2^53)
+    iso_int = 0
+    try:
+        if float(iso) == int(iso):
+            iso_int = int(iso)
+    except (OverflowError, ValueError):
+        pass
+    iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
     return _abi.Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                       float(relax), int(max_steps), int(bool(q1)), int(variant), 0)
+                       float(relax), int(max_steps), int(bool(q1)), int(variant), 0, iso_int)
 
 
 def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
@@ -125,6 +134,10 @@ class Extractor:
         torch = _torch()
         s = torch.cuda.current_stream(self.device).cuda_stream
         _abi.check(self._ctx, self._lib.cuberille_set_stream(self._ctx, C.c_void_p(s)))
+
+    def use_stream(self, torch_stream):
+        """Order this context's work on a torch.cuda.Stream of the caller's."""
+        _abi.check(self._ctx, self._lib.cuberille_set_stream(self._ctx, C.c_void_p(torch_stream.cuda_stream)))
 
     def use_own_stream(self):
         """Back to the context's own stream (the default)."""
@@ -197,12 +210,42 @@ class Extractor:
         """Start the offset-free part of the emit (vertex scatter, projection) right after count(); returns at once."""
         _abi.check(self._ctx, self._lib.cuberille_emit_points(self._ctx))
 
-    def emit(self, point_id_offset=0, cell_id_offset=0):
+    def emit(self, point_id_offset=0):
         res = _abi.Result()
-        _abi.check(self._ctx, self._lib.cuberille_emit(self._ctx, int(point_id_offset), int(cell_id_offset),
-                                                       C.byref(res)))
+        _abi.check(self._ctx, self._lib.cuberille_emit(self._ctx, int(point_id_offset), C.byref(res)))
         self.result = res
         return res
+
+    def step_begin(self, dev_ptr, desc, params, slab=None):
+        """Count and the offset-free part of the emit, launched back to back without waiting (cuberille_step_begin).
+        Returns (device pointer, bytes) of this rank's row, to be all-gathered in rank order."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _abi.check(self._ctx, self._lib.cuberille_step_begin(
+            self._ctx, C.byref(desc), C.c_void_p(dev_ptr), C.byref(params),
+            C.byref(slab) if slab is not None else None, C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
+    def step_end(self, dev_rows, n_ranks, rank):
+        """The cells with the id offset computed on the device from the gathered rows, then the one wait of the step.
+        Returns (result, done): done is False (CUBERILLE_RETRY) when a flag on some rank sends every rank to the
+        synchronous calls; the result then only holds the counts."""
+        res = _abi.Result()
+        rc = self._lib.cuberille_step_end(self._ctx, C.c_void_p(dev_rows), int(n_ranks), int(rank), C.byref(res))
+        if rc == _abi.RETRY:
+            return res, False
+        _abi.check(self._ctx, rc)
+        self.result = res
+        return res, True
+
+    def escaped_count(self):
+        """THIN_HALO slabs, after emit_points(): walks that left the buffer (waits for the vertex phase)."""
+        n = C.c_uint64()
+        _abi.check(self._ctx, self._lib.cuberille_escaped_count(self._ctx, C.byref(n)))
+        return _abi.ESCAPED_OVERFLOW if n.value == 2 ** 64 - 1 else int(n.value)
+
+    def reproject_escaped(self, dev_ptr, z_begin, nz):
+        """Walk the escaped vertices again in a buffer that holds the full halo (slices [z_begin, z_begin + nz))."""
+        _abi.check(self._ctx, self._lib.cuberille_reproject_escaped(self._ctx, C.c_void_p(dev_ptr), int(z_begin), int(nz)))
 
     # -- results -----------------------------------------------------------------------------
     def download(self, out=None):
@@ -281,6 +324,15 @@ def required_halo(desc, params):
     rc = _abi.lib().cuberille_required_halo(C.byref(desc), C.byref(params), C.byref(lo), C.byref(hi))
     if rc != _abi.OK:
         raise _abi.CuberilleError(rc, "cuberille_required_halo: bad image description or parameters")
+    return int(lo.value), int(hi.value)
+
+
+def minimum_halo(desc, params):
+    """The least a THIN_HALO slab must hold (below, above) its owned range (needs no GPU)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    rc = _abi.lib().cuberille_minimum_halo(C.byref(desc), C.byref(params), C.byref(lo), C.byref(hi))
+    if rc != _abi.OK:
+        raise _abi.CuberilleError(rc, "cuberille_minimum_halo: bad image description or parameters")
     return int(lo.value), int(hi.value)
 
 

@@ -30,22 +30,32 @@ def slab_range(global_nz, world, rank):
     return z0, z0 + base + (1 if rank < rem else 0)
 
 
+def _pair(halo):
+    """A halo as (slices below, slices above); a plain number means both."""
+    if isinstance(halo, (tuple, list)):
+        return int(halo[0]), int(halo[1])
+    return int(halo), int(halo)
+
+
 def buffer_range(global_nz, z0, z1, halo=HALO):
-    """Slices [lo, hi) a rank keeps in memory: its own plus the halo that exists."""
-    return max(z0 - halo, 0), min(z1 + halo, int(global_nz))
+    """Slices [lo, hi) a rank keeps in memory: its own plus the halo (a number, or (below, above)) that exists."""
+    below, above = _pair(halo)
+    return max(z0 - below, 0), min(z1 + above, int(global_nz))
 
 
-def halo_transfers(global_nz, world, rank, halo=HALO):
+def halo_transfers(global_nz, world, rank, halo=HALO, held=0):
     """The point-to-point transfers of one halo exchange as this rank sees them: (recvs, sends), each a list of
-    (peer, z_first, z_last_exclusive) in global slices.  A rank needs [z0 - halo, z0) and [z1, z1 + halo) clipped to
+    (peer, z_first, z_last_exclusive) in global slices.  A rank needs [z0 - below, z0) and [z1, z1 + above) clipped to
     the volume; every slice of that comes from the rank that owns it -- the two neighbours when the slabs are at least
-    `halo` thick, more ranks when they are thinner (thin slabs, long walks)."""
+    `halo` thick, more ranks when they are thinner (thin slabs, long walks).  held: the part of the halo every rank has
+    already (the thin halo of a first exchange): only what lies beyond it is moved."""
     ranges = [slab_range(global_nz, world, r) for r in range(world)]
     bufs = [buffer_range(global_nz, a, b, halo) for a, b in ranges]
+    have = [buffer_range(global_nz, a, b, held) for a, b in ranges]
 
     def needs(r):                                   # the two halo parts of rank r
-        (a, b), (lo, hi) = ranges[r], bufs[r]
-        return [(lo, a), (b, hi)]
+        (lo, hi), (hlo, hhi) = bufs[r], have[r]
+        return [(lo, hlo), (hhi, hi)]
     recvs, sends = [], []
     z0, z1 = ranges[rank]
     for s in range(world):
@@ -63,27 +73,31 @@ def halo_transfers(global_nz, world, rank, halo=HALO):
     return recvs, sends
 
 
-def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None):
-    """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry.
-    Fills [lo, z0) and [z1, hi) from the ranks that own those slices.  All ranks call it together.
-    wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
+def halo_bytes(global_nz, world, rank, slice_bytes, halo=HALO, held=0):
+    """Bytes this rank receives in one halo exchange of that shape."""
+    recvs, _ = halo_transfers(global_nz, world, rank, halo, held)
+    return sum(b - a for _, a, b in recvs) * int(slice_bytes)
+
+
+def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None, held=0):
+    """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry (and, held, that much halo
+    around it).  Fills the rest of the halo (a number, or (below, above)) from the ranks that own those slices.  All
+    ranks call it together.  wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
     import torch.distributed as dist
     if buf.is_cuda and dist.get_backend(group) == "gloo" and wait:
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
         host = buf.cpu()
-        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo, global_nz=global_nz)
-        if z0 > lo:
-            buf[:z0 - lo].copy_(host[:z0 - lo])
-        if hi > z1:
-            buf[z1 - lo:].copy_(host[z1 - lo:])
+        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo, global_nz=global_nz, held=held)
+        buf.copy_(host)
         return buf
     if global_nz is None:
         # callers that only know their own ranges: the classic two-neighbour exchange (slabs >= halo thick)
+        h = _pair(halo)[0]
         recvs = ([(rank - 1, lo, z0)] if rank > 0 and z0 > lo else []) + ([(rank + 1, z1, hi)] if rank < world - 1 and hi > z1 else [])
-        sends = ([(rank + 1, z1 - min(halo, z1 - z0), z1)] if rank < world - 1 and hi > z1 else []) + \
-                ([(rank - 1, z0, z0 + min(halo, z1 - z0))] if rank > 0 and z0 > lo else [])
+        sends = ([(rank + 1, z1 - min(h, z1 - z0), z1)] if rank < world - 1 and hi > z1 else []) + \
+                ([(rank - 1, z0, z0 + min(h, z1 - z0))] if rank > 0 and z0 > lo else [])
     else:
-        recvs, sends = halo_transfers(global_nz, world, rank, halo)
+        recvs, sends = halo_transfers(global_nz, world, rank, halo, held)
     ops, keep = [], []
     for peer, a, b in recvs:
         ops.append(dist.P2POp(dist.irecv, buf[a - lo:b - lo], peer, group))
@@ -151,7 +165,7 @@ def id_offsets(counts, rank):
 
 
 # columns of the per-rank row that travels in the count all-gather
-ROW_POINTS, ROW_CELLS, ROW_ALIAS_Z, ROW_TOP, ROW_TOP2, ROW_FAILED = range(6)
+ROW_POINTS, ROW_CELLS, ROW_ALIAS_Z, ROW_TOP, ROW_TOP2, ROW_FAILED, ROW_ESCAPED = range(7)
 
 
 def alias_plan(rows, bounds=None):
@@ -218,98 +232,209 @@ class ShardedExtractor:
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
-                 cross_slab_aliasing=True):
+                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
         nothing extra, the flags ride in the count all-gather -- and, cross_slab_aliasing, reproduce it: the rank below
         sends the source slice's inside bits (the rank above counts again), later the ids and positions of that slice's
         top-plane vertices; with cross_slab_aliasing off the case raises instead.  check_aliasing off returns whatever
-        the ranks computed on their own (a mesh that differs from the single-GPU one in that case)."""
+        the ranks computed on their own (a mesh that differs from the single-GPU one in that case).
+        thin_halo (needs params): every step exchanges only the slices a vertex needs where it STARTS
+        (cuberille_minimum_halo) plus `guard` more on each side; a walk that wants a slice beyond that is put aside by
+        the library, and only then -- the count of such walks rides in the count all-gather -- the ranks fetch the rest
+        of the full halo and walk those vertices again.  The buffer is sized for the full halo either way.
+        device_offsets (GPU buffers only): the step without a host round trip between count and emit
+        (cuberille_step_begin / _end) -- the all-gather of the per-rank rows lands in device memory and the cell pass sums
+        its id offset there; the host waits once per step.  A flag in any row (quirk Q1 across slabs, counts beyond the
+        sizes guessed from the previous step, an escaped walk) sends every rank through the synchronous protocol."""
         from . import _abi
-        from .cuberille import make_desc, required_halo
+        from .cuberille import make_desc, minimum_halo, required_halo
         self.ex = extractor
         self.rank, self.world, self.group = rank, world, group
         self.nx, self.ny, self.nz = (int(v) for v in global_dims)
         self.z0, self.z1 = slab_range(self.nz, world, rank)
         self._geo = (np_dtype, spacing, origin, direction)
+        whole = make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction)
         if halo is None:
             halo = HALO
             if params is not None:
-                halo = max(required_halo(make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction), params))
+                halo = max(required_halo(whole, params))
         self.halo = int(halo)
         self.lo, self.hi = buffer_range(self.nz, self.z0, self.z1, self.halo)
         if world > self.nz:
             raise ValueError("more ranks (%d) than slices (%d)" % (world, self.nz))
         self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
         self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None, None)
+        # the thin form of the same slab: a window of the same buffer
+        self.thin = None
+        if thin_halo and world > 1:
+            if params is None:
+                raise ValueError("thin_halo needs params (the halo's two sizes follow from them)")
+            below, above = minimum_halo(whole, params)
+            t = (min(below + int(guard), self.halo), min(above + int(guard), self.halo))
+            if t[0] < self.halo or t[1] < self.halo:          # (else there is nothing to save)
+                self.thin = t
+                self.tlo, self.thi = buffer_range(self.nz, self.z0, self.z1, t)
+                self.thin_desc = make_desc(np_dtype, (self.nx, self.ny, self.thi - self.tlo), spacing, origin, direction)
+                self.thin_slab = _abi.Slab(self.nz, self.tlo, self.z0, self.z1, 0, _abi.SLAB_THIN_HALO, None, None)
+        self.itemsize = int(np.dtype(np_dtype).itemsize)
         self._halo_event = None
         self.force_event_path = False             # tests: the non-blocking exchange + event hand-off without RCCL
         self._vox_event = None
         self.check_aliasing = check_aliasing
         self.cross_slab_aliasing = cross_slab_aliasing
         self.counts = None
+        self.device_offsets = bool(device_offsets)
+        self._lib_stream = None                   # device_offsets: the library's work goes to a torch stream of ours
+        self._rows = None
+        self._lazy_counts = None
+        self._ev = None
+        # what the last extract() cost besides kernels (bench.py prints them)
+        self.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+
+    # -- halo exchange -------------------------------------------------------------------------------------------
+    def _exchange(self, buf, halo, held, slab):
+        """Fill the halo (beyond what `held` says is there) and tell `slab` how to wait for it: on the host (gloo), or
+        through two events (RCCL: the library runs on its own stream and thresholds the owned slices meanwhile)."""
+        import torch
+        import torch.distributed as dist
+        self.stats["halo_bytes"] += halo_bytes(self.nz, self.world, self.rank, self.nx * self.ny * self.itemsize, halo, held)
+        # (self.force_event_path: take the event branch under gloo too -- what the tests on one-GPU boxes set)
+        if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or self.force_event_path):
+            if self._vox_event is None:
+                self._vox_event = torch.cuda.Event()
+                self._halo_event = torch.cuda.Event()
+            self._vox_event.record(torch.cuda.current_stream())
+            reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
+                                        wait=False, halo=halo, global_nz=self.nz, held=held)
+            for req in reqs:
+                req.wait()                     # orders torch's current stream behind the transfer, not the host
+            self._halo_event.record(torch.cuda.current_stream())
+            slab.voxels_ready_event = self._vox_event.cuda_event
+            slab.halo_ready_event = self._halo_event.cuda_event
+            return keep
+        exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=halo,
+                       global_nz=self.nz, held=held)
+        if buf.is_cuda:
+            torch.cuda.current_stream().synchronize()
+            self.stats["host_syncs"] += 1
+        slab.halo_ready_event = None
+        slab.voxels_ready_event = None
+        return None
 
     def extract(self, buf, params):
         """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid (written on torch's current stream).
         Runs halo exchange, count, the count all-gather and emit; leaves this rank's mesh part on its device."""
         import torch
-        import torch.distributed as dist
-        from . import _abi
         from .cuberille import required_halo
-        keep = None
-        if self.world > 1:
-            need = max(required_halo(self.desc, params))
-            if need > self.halo:
-                raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "
-                                 "with a halo of %d (pass params= or halo= to its constructor)" % (need, self.halo))
-            # (self.force_event_path: take this branch under gloo too -- what the tests on one-GPU boxes set)
-            if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or self.force_event_path):
-                # RCCL: do not wait on the host.  The library runs on its own stream: one event tells it when the
-                # owned slices (produced on torch's current stream) are valid, a second one, recorded behind the
-                # transfers, when the halo slices are in; it thresholds the owned slices meanwhile.
-                if self._vox_event is None:
-                    self._vox_event = torch.cuda.Event()
-                    self._halo_event = torch.cuda.Event()
-                self._vox_event.record(torch.cuda.current_stream())
-                reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
-                                            wait=False, halo=self.halo, global_nz=self.nz)
-                for req in reqs:
-                    req.wait()                     # orders torch's current stream behind the transfer, not the host
-                self._halo_event.record(torch.cuda.current_stream())
-                self.slab.voxels_ready_event = self._vox_event.cuda_event
-                self.slab.halo_ready_event = self._halo_event.cuda_event
-            else:
-                exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=self.halo,
-                               global_nz=self.nz)
-                if buf.is_cuda:
-                    torch.cuda.current_stream().synchronize()
-                self.slab.halo_ready_event = None
-                self.slab.voxels_ready_event = None
-        elif buf.is_cuda:
-            torch.cuda.current_stream().synchronize()
+        self.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
         if self.world == 1:
+            if buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
             n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, None)
             self.counts = np.array([[n_p, n_c]], dtype=np.int64)
-            return self.ex.emit(0, 0)
+            self.stats["host_syncs"] = 3 if buf.is_cuda else 0
+            return self.ex.emit(0)
+        need = max(required_halo(self.desc, params))
+        if need > self.halo:
+            raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "
+                             "with a halo of %d (pass params= or halo= to its constructor)" % (need, self.halo))
+        thin = self.thin is not None and bool(params.project_vertices) and int(params.projection_variant) == 0
+        if self.device_offsets and buf.is_cuda and hasattr(self.ex, "step_begin"):
+            return self._extract_step(buf, params, thin)
+        return self._extract_sync(buf, params, thin, held=0)
+
+    def _extract_step(self, buf, params, thin):
+        """One step with ONE host wait: exchange -> [count, vertex phase] -> all-gather of the rows in device memory ->
+        cells with the offset summed on the device.  The library works on a stream of ours; events order it against
+        torch's current stream, where the collectives are enqueued."""
+        import torch
+        import torch.distributed as dist
+        dev = buf.device
+        if self._lib_stream is None:
+            self._lib_stream = torch.cuda.Stream(device=dev)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+            self.ex.use_stream(self._lib_stream)
+        cur, ls = torch.cuda.current_stream(), self._lib_stream
+        if thin:
+            slab, desc, halo = self.thin_slab, self.thin_desc, self.thin
+            base = buf[self.tlo - self.lo:self.thi - self.lo]
+        else:
+            slab, desc, halo, base = self.slab, self.desc, self.halo, buf
+        keep = self._exchange(buf, halo, 0, slab)
+        if slab.voxels_ready_event is None:
+            ls.wait_stream(cur)                    # (host-waited exchange: the buffer is ready, order the streams all the same)
+        ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
+        nw = nbytes // 8
+        row = _words_view(ptr, nw, dev)
+        if self._rows is None or self._rows.numel() != self.world * nw:
+            self._rows = torch.empty(self.world * nw, dtype=torch.int64, device=dev)
+        self._ev[0].record(ls)
+        cur.wait_event(self._ev[0])
+        if dist.get_backend(self.group) == "gloo":
+            # rehearsal on one GPU: the rows go through the host (a wait that RCCL does not need)
+            host = torch.empty(self.world * nw, dtype=torch.int64)
+            dist.all_gather_into_tensor(host, row.cpu(), group=self.group)
+            self._rows.copy_(host)
+            self.stats["host_syncs"] += 1
+        else:
+            dist.all_gather_into_tensor(self._rows, row, group=self.group)
+        self.stats["collectives"] += 1
+        self._ev[1].record(cur)
+        ls.wait_event(self._ev[1])
+        res, done = self.ex.step_end(self._rows.data_ptr(), self.world, self.rank)
+        self.stats["host_syncs"] += 1
+        del keep
+        if done:
+            # (the offsets were never on the host: gather_mesh reads the counts from the rows that step_end brought back)
+            self.counts = None
+            self._lazy_counts = (nw, 2 if int(params.generate_triangles) else 1)
+            return res
+        # a flag somewhere: every rank goes on from its finished count with the host in the loop
+        return self._extract_sync(buf, params, thin, held=halo, resume=(int(res.n_points), int(res.n_cells)))
+
+    def _extract_sync(self, buf, params, thin, held, resume=None):
+        """One step with the host in the loop: exchange, count, (vertex phase), all-gather of the counts, cells.
+        resume=(n_points, n_cells): the count is done already (a step that came back with CUBERILLE_RETRY)."""
+        import torch
+        from . import _abi
+        dev = buf.device
+        if thin:
+            slab, desc, halo = self.thin_slab, self.thin_desc, self.thin
+            base = buf[self.tlo - self.lo:self.thi - self.lo]
+        else:
+            slab, desc, halo, base = self.slab, self.desc, self.halo, buf
+        keep = self._exchange(buf, halo, held, slab) if _pair(halo) != _pair(held) else None
         # a failure on one rank must not leave the others waiting in the all-gather: it travels with the counts
         n_p = n_c = 0
+        n_esc = 0
         info, failed = None, None
         try:
-            n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, self.slab)
+            if resume is not None:
+                n_p, n_c = resume
+            else:
+                n_p, n_c = self.ex.count(base.data_ptr(), desc, params, slab)
+                self.stats["host_syncs"] += 1
             if self.check_aliasing and params.emulate_empty_slice_aliasing:
                 info = self.ex.slab_info()
             if info is None or info.alias_z < 0:
                 # nothing another rank says can change this rank's counts: the vertices are scattered and projected
                 # while the counts are gathered, only the cells wait for the id offsets
                 self.ex.emit_points()
+                if thin:
+                    # ... unless walks may have left the thin halo: their number has to travel with the counts
+                    n_esc = self.ex.escaped_count()
+                    self.stats["host_syncs"] += 1
         except _abi.CuberilleError as e:
             failed = e
         del keep
-        dev = buf.device
         rows = gather_counts(n_p, n_c, dev, self.group, extra=(
             info.alias_z if info is not None else -1, info.highest if info is not None else -1,
-            info.second_highest if info is not None else -1, 0 if failed is None else 1))
+            info.second_highest if info is not None else -1, 0 if failed is None else 1, n_esc))
+        self.stats["collectives"] += 1
+        if dev.type == "cuda":
+            self.stats["host_syncs"] += 1
         self.counts = rows[:, :2]
         self._raise_if_any_failed(rows[:, ROW_FAILED], "cuberille_count", failed)
         # quirk Q1 across slab boundaries: rank r assumed that nothing is occupied below its buffer; a rank below says
@@ -318,6 +443,26 @@ class ShardedExtractor:
         plan = alias_plan(rows, bounds) if self.check_aliasing else []
         if plan and not self.cross_slab_aliasing:
             raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % plan[0][0])
+        if thin:
+            escaped = rows[:, ROW_ESCAPED]
+            self.stats["escaped"] = int(n_esc)
+            overflow = (escaped >= _abi.ESCAPED_OVERFLOW).any()
+            if plan or overflow or escaped.any():
+                # the rare way: every rank completes its halo to the full one ...
+                self.stats["deep_halo_fetched"] = True
+                keep = self._exchange(buf, self.halo, self.thin, self.slab)
+                if dev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()     # (the re-projection reads the new slices at once)
+                del keep
+                if plan or overflow:
+                    # ... and the step is taken again on it (quirk Q1 crossing a boundary, or more escapes than the
+                    # library's list holds): the hand-over protocol below then runs on full buffers only
+                    return self._extract_sync(buf, params, False, held=self.halo)
+                try:
+                    if n_esc:                                  # ... or only the escaped vertices are walked again
+                        self.ex.reproject_escaped(buf.data_ptr(), self.lo, self.hi - self.lo)
+                except _abi.CuberilleError as e:
+                    failed = e
         n_words = self.ny * ((self.nx + 63) // 64)
         n_corners = (self.nx + 1) * (self.ny + 1)
         for r, src, zp, _ in plan:
@@ -362,7 +507,7 @@ class ShardedExtractor:
                     raise RuntimeError("the rank serving the re-used vertices (rank %d) failed" % src)
                 self.ex.set_alias_plane(ids.data_ptr(), pts.data_ptr())
                 planes = (ids, pts)
-            res = self.ex.emit(poff, coff)
+            res = self.ex.emit(poff)
         except (_abi.CuberilleError, RuntimeError) as e:
             failed = failed or e
         del planes
@@ -402,6 +547,10 @@ class ShardedExtractor:
         import torch
         import torch.distributed as dist
         from .cuberille import Mesh
+        if self.counts is None and self._lazy_counts is not None:
+            nw, tri = self._lazy_counts
+            t = self._rows.view(self.world, nw).cpu().numpy()       # the rows of the last step: totV, totQ, V0, Q0, ...
+            self.counts = np.stack([t[:, 0] - t[:, 2], (t[:, 1] - t[:, 3]) * tri], 1).astype(np.int64)
         if self.counts is None:
             raise RuntimeError("gather_mesh before extract")
         counts = np.asarray(self.counts, dtype=np.int64)

@@ -105,8 +105,10 @@ public:
   /** The image to polygonize (reference h:184, txx:53-56). */
   virtual void SetInput(const InputImageType *inputImage);
 
-  /** Interpolator (reference h:187-188).  The GPU path implements
-   *  LinearInterpolateImageFunction<TInputImage,double>; any other type makes Update() throw. */
+  /** Interpolator (reference h:187-188).  The kernels implement LinearInterpolateImageFunction<TInputImage,double>;
+   *  with any other type the GPU still does the topology and the lattice points, and the walk of txx:439-474 runs on
+   *  the host through the user's Evaluate() -- on the calling thread, as the reference does (txx:455), unless
+   *  SetHostWalkThreads asks for more (the interpolator must then be safe to call from several threads at once). */
   itkGetObjectMacro(Interpolator, InterpolatorType);
   itkSetObjectMacro(Interpolator, InterpolatorType);
 
@@ -136,8 +138,8 @@ public:
   itkSetMacro(Device, int);
   itkGetMacro(LastDeviceSeconds, double);
   /** Not in the reference: seconds the last GenerateData() spent pouring the flat buffers into the output
-   *  mesh (one heap cell per face, as the reference's txx:310-329 does), and a way around that cost for
-   *  callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
+   *  mesh (ITK-lite: one adopted cell array; real ITK: one heap cell per face, as the reference's txx:310-329
+   *  does), and a way around that cost for callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
    *  polydata itk::VTKPolyDataWriter would give for GetOutput(), straight from the device buffers. */
   itkGetMacro(LastMeshFillSeconds, double);
   /** Wall time of the last update's cuberille_extract_host call (upload overlapped with the sweep, then the rest
@@ -148,6 +150,11 @@ public:
   /** Not in the reference: seconds the device of this filter takes to receive `bytes` from pinned host memory
    *  (cuberille_debug_h2d_seconds) -- what the upload inside Update() is measured against. */
   double MeasureHostToDeviceSeconds(unsigned long long bytes);
+  /** Not in the reference: host threads of the walk taken for a TInterpolator the kernels do not implement.
+   *  Default 1 -- the reference calls Evaluate() from one thread (txx:455) and an interpolator may keep mutable
+   *  state; more only for interpolators whose Evaluate() const is thread-safe. */
+  itkGetMacro(HostWalkThreads, unsigned int);
+  itkSetClampMacro(HostWalkThreads, unsigned int, 1u, 256u);
 
 protected:
   CuberilleImageToMeshFilter();
@@ -171,6 +178,7 @@ private:
   double m_ProjectVertexStepLengthRelaxationFactor;
   unsigned int m_ProjectVertexMaximumNumberOfSteps;
   int m_Device;
+  unsigned int m_HostWalkThreads;
   double m_LastDeviceSeconds;
   double m_LastMeshFillSeconds;
   double m_LastExtractSeconds;

@@ -15,6 +15,7 @@
 #include <vector>
 #if __cplusplus >= 201103L
 #include <chrono>
+#include <exception>
 #include <thread>
 #endif
 
@@ -33,6 +34,18 @@ template <> struct PixelCode<unsigned int>   { enum { Value = CUBERILLE_PIX_U32 
 template <> struct PixelCode<int>            { enum { Value = CUBERILLE_PIX_I32 }; };
 template <> struct PixelCode<float>          { enum { Value = CUBERILLE_PIX_F32 }; };
 template <> struct PixelCode<double>         { enum { Value = CUBERILLE_PIX_F64 }; };
+// the 64-bit integer types: long / unsigned long where they are 64 bits wide (LP64), long long everywhere
+template <> struct PixelCode<long>               { enum { Value = sizeof(long) == 8 ? CUBERILLE_PIX_I64 : CUBERILLE_PIX_I32 }; };
+template <> struct PixelCode<unsigned long>      { enum { Value = sizeof(long) == 8 ? CUBERILLE_PIX_U64 : CUBERILLE_PIX_U32 }; };
+template <> struct PixelCode<long long>          { enum { Value = CUBERILLE_PIX_I64 }; };
+template <> struct PixelCode<unsigned long long> { enum { Value = CUBERILLE_PIX_U64 }; };
+
+// cuberille_params::iso_value_int: the iso value of those types as an integer (a double cannot hold it past 2^53)
+template <class T> struct IsoInt { static int64_t Get(T) { return 0; } };
+template <> struct IsoInt<long>               { static int64_t Get(long v) { return static_cast<int64_t>(v); } };
+template <> struct IsoInt<unsigned long>      { static int64_t Get(unsigned long v) { return static_cast<int64_t>(v); } };
+template <> struct IsoInt<long long>          { static int64_t Get(long long v) { return static_cast<int64_t>(v); } };
+template <> struct IsoInt<unsigned long long> { static int64_t Get(unsigned long long v) { return static_cast<int64_t>(v); } };
 
 inline double WallSeconds()
 {
@@ -43,17 +56,28 @@ inline double WallSeconds()
 #endif
 }
 
-// f(i) for the ranges [i0, i1) of a few host threads (the mesh fill is a plain copy into independent elements)
-template <class F> void ParallelRanges(uint64_t n, F f)
+// f(i0, i1) over the ranges of `nT` host threads (0: a few, for plain copies into independent elements).  An exception
+// thrown inside a worker is carried to the calling thread and rethrown after the join.
+template <class F> void ParallelRanges(uint64_t n, F f, unsigned int nT = 0)
 {
 #if __cplusplus >= 201103L
-  unsigned int hw = std::thread::hardware_concurrency();
-  const unsigned int nT = n < 65536 ? 1u : (hw >= 16 ? 8u : (hw >= 2 ? hw / 2 : 1u));
-  if (nT > 1)
+  if (nT == 0)
+    {
+    const unsigned int hw = std::thread::hardware_concurrency();
+    nT = n < 65536 ? 1u : (hw >= 16 ? 8u : (hw >= 2 ? hw / 2 : 1u));
+    }
+  if (nT > 1 && n >= nT)
     {
     std::vector<std::thread> th;
-    for (unsigned int t = 0; t < nT; t++) th.push_back(std::thread(f, n * t / nT, n * (t + 1) / nT));
+    std::vector<std::exception_ptr> thrown(nT);
+    for (unsigned int t = 0; t < nT; t++)
+      {
+      std::exception_ptr *slot = &thrown[t];
+      const uint64_t i0 = n * t / nT, i1 = n * (t + 1) / nT;
+      th.push_back(std::thread([f, i0, i1, slot]() { try { f(i0, i1); } catch (...) { *slot = std::current_exception(); } }));
+      }
     for (unsigned int t = 0; t < nT; t++) th[t].join();
+    for (unsigned int t = 0; t < nT; t++) if (thrown[t]) std::rethrow_exception(thrown[t]);
     return;
     }
 #endif
@@ -292,6 +316,7 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_ProjectVertexStepLengthRelaxationFactor = 0.95;
   m_ProjectVertexMaximumNumberOfSteps = 50;
   m_Device = 0;
+  m_HostWalkThreads = 1;
   m_LastDeviceSeconds = 0.0;
   m_LastMeshFillSeconds = 0.0;
   m_LastExtractSeconds = 0.0;
@@ -359,6 +384,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   prm.projection_variant = USE_ADVANCED_PROJECTION ? CUBERILLE_PROJECT_ADVANCED
                          : (USE_LINESEARCH_PROJECTION ? CUBERILLE_PROJECT_LINESEARCH : CUBERILLE_PROJECT_DEFAULT);
   prm.reserved = 0;
+  prm.iso_value_int = cuberille_detail::IsoInt<InputPixelType>::Get(m_IsoSurfaceValue);
   if (hostWalk && m_ProjectVerticesToIsoSurface && prm.projection_variant != CUBERILLE_PROJECT_DEFAULT)
     itkExceptionMacro(<< "USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION are only offered with the default "
                          "LinearInterpolateImageFunction");
@@ -392,7 +418,17 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
       {&gradient, m_Interpolator.GetPointer(), points, static_cast<double>(m_IsoSurfaceValue),
        m_ProjectVertexSurfaceDistanceThreshold, m_ProjectVertexStepLength, m_ProjectVertexStepLengthRelaxationFactor,
        m_ProjectVertexMaximumNumberOfSteps};
-    cuberille_detail::ParallelRanges(res.n_points, walk);
+    // on the calling thread unless the user vouched for the interpolator (SetHostWalkThreads); whatever Evaluate()
+    // throws leaves through Update() like any other exception of the pipeline
+    try
+      {
+      cuberille_detail::ParallelRanges(res.n_points, walk, m_HostWalkThreads);
+      }
+    catch (...)
+      {
+      std::free(points); std::free(cells);
+      throw;
+      }
     if (m_GenerateTriangleFaces)
       {
       uint64_t *tri = static_cast<uint64_t *>(std::malloc(sizeof(uint64_t) * (res.n_cells * 6 + 1)));

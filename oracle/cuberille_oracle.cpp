@@ -29,6 +29,7 @@
 #include <map>
 #include <memory>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -44,7 +45,7 @@ struct Geometry {
 
 // 3x3 inverse by cofactors.  ITK uses vnl's SVD-based inverse; for the identity
 // direction / axis-aligned spacing of every shipped volume both are exact.
-// The product library uses the same formula (csrc/cuberille_host.cpp) so that the
+// The product library uses the same formula (csrc/cuberille_api.hip, invert3) so that the
 // matrix entries handed to both sides are the same doubles.
 void invert3(const double m[9], double inv[9]) {
   const double c00 = m[4] * m[8] - m[5] * m[7];
@@ -497,7 +498,9 @@ int run_typed(const oracle_image *img, const oracle_params *prm, oracle_mesh *ou
   f.im.g = make_geometry(img);
   f.im.px = (const T *)img->voxels;
   f.prm = *prm;
-  f.iso = (T)prm->iso_value;
+  // m_IsoSurfaceValue is an InputPixelType (h:180-181); the 64-bit integer types get theirs as an integer
+  if (std::is_integral<T>::value && sizeof(T) == 8) f.iso = (T)prm->iso_value_int;
+  else f.iso = (T)prm->iso_value;
   double t0 = now_s();
   if (prm->project_vertices) f.ComputeGradientImage();                        // txx:95,484
   double t1 = now_s();
@@ -538,6 +541,8 @@ auto dispatch(int pixel_type, F &&fn, int &err) {
     case ORACLE_PIX_I32: return fn((int32_t *)nullptr);
     case ORACLE_PIX_F32: return fn((float *)nullptr);
     case ORACLE_PIX_F64: return fn((double *)nullptr);
+    case ORACLE_PIX_I64: return fn((int64_t *)nullptr);
+    case ORACLE_PIX_U64: return fn((uint64_t *)nullptr);
   }
   err = 1;
   return fn((uint8_t *)nullptr);
@@ -545,7 +550,7 @@ auto dispatch(int pixel_type, F &&fn, int &err) {
 
 bool valid_image(const oracle_image *img) {
   if (!img || !img->voxels) return false;
-  if (img->pixel_type < 0 || img->pixel_type > ORACLE_PIX_F64) return false;
+  if (img->pixel_type < 0 || img->pixel_type > ORACLE_PIX_U64) return false;
   for (int i = 0; i < 3; i++) if (img->dims[i] < 1 || !(img->spacing[i] > 0.0)) return false;
   return true;
 }

@@ -29,7 +29,8 @@ extern "C" {
 /* Pixel type codes: shared numbering with include/cuberille_hip.h */
 enum {
   ORACLE_PIX_U8 = 0, ORACLE_PIX_I8 = 1, ORACLE_PIX_U16 = 2, ORACLE_PIX_I16 = 3,
-  ORACLE_PIX_U32 = 4, ORACLE_PIX_I32 = 5, ORACLE_PIX_F32 = 6, ORACLE_PIX_F64 = 7
+  ORACLE_PIX_U32 = 4, ORACLE_PIX_I32 = 5, ORACLE_PIX_F32 = 6, ORACLE_PIX_F64 = 7,
+  ORACLE_PIX_I64 = 8, ORACLE_PIX_U64 = 9      /* long / unsigned long pixels: h:150 takes any InputPixelType */
 };
 
 typedef struct {
@@ -54,6 +55,8 @@ typedef struct {
   int32_t projection_variant;    /* 0: the default branch (txx:439-474); 1: USE_ADVANCED_PROJECTION (txx:340-397);
                                     2: USE_LINESEARCH_PROJECTION (txx:398-437) -- both compiled out upstream (h:22-23) */
   int32_t reserved;
+  int64_t iso_value_int;         /* ORACLE_PIX_I64 / _U64: the iso value itself (m_IsoSurfaceValue is an InputPixelType,
+                                    h:180-181; a double cannot hold it past 2^53); _U64: the same 64 bits as unsigned */
 } oracle_params;
 
 typedef struct {

@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "_build", "libcuberille_oracle.so")
 PIXEL_CODES = {
     np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3,
     np.dtype(np.uint32): 4, np.dtype(np.int32): 5, np.dtype(np.float32): 6, np.dtype(np.float64): 7,
+    np.dtype(np.int64): 8, np.dtype(np.uint64): 9,
 }
 
 
@@ -28,7 +29,7 @@ class _Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
                 ("max_steps", C.c_uint32), ("gradient_threads", C.c_int32), ("faithful_cells", C.c_int32),
-                ("projection_variant", C.c_int32), ("reserved", C.c_int32)]
+                ("projection_variant", C.c_int32), ("reserved", C.c_int32), ("iso_value_int", C.c_int64)]
 
 
 class _Mesh(C.Structure):
@@ -93,8 +94,15 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  variant: 0 the default projection,
     1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches."""
     img, keep = _image(vol, spacing, origin, direction)
+    iso_int = 0
+    try:
+        if float(iso) == int(iso):
+            iso_int = int(iso)
+    except (OverflowError, ValueError):
+        pass
+    iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
     prm = _Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), 0)
+                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), 0, iso_int)
     mesh = _Mesh()
     rc = lib().cuberille_oracle_run(C.byref(img), C.byref(prm), C.byref(mesh))
     if rc != 0:

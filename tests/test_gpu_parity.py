@@ -183,7 +183,7 @@ def test_slabs_concatenate_to_the_whole(pkg, oracle, extractor, volumes):
                 desc = pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo))
                 slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
                 n_p, n_c = extractor.count(slab_vox.data_ptr(), desc, prm, slab)
-                extractor.emit(poff, 0)
+                extractor.emit(poff)
                 m = extractor.download()
                 assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
                 pts.append(m.points)
@@ -449,7 +449,7 @@ def test_1024_marschner_lobb_properties(pkg, extractor):
         sdesc = pkg.make_desc(np.float32, (n, n, hi - lo))
         slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
         n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), sdesc, prm, slab)
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -485,7 +485,7 @@ def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, vol
         desc = pkg.make_desc(np.uint8, (nx, ny, hi - lo))
         slab = pkg._abi.Slab(nz, lo, a, b, 0, 0, ev.cuda_event)
         n_p, n_c = extractor.count(buf.data_ptr(), desc, prm, slab)
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -584,7 +584,7 @@ def test_noise_u8_config5_properties(pkg, extractor):
         lo, hi = max(a - 8, 0), min(b + 8, n)
         slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
         n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (n, n, hi - lo)), prm, slab)
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -622,7 +622,7 @@ def test_2048_noise_u8_config5_full_size(pkg, extractor):
         lo, hi = max(a - 8, 0), min(b + 8, n)
         slab = pkg._abi.Slab(n, lo, a, b, 0, 0)
         n_p, n_c = extractor.count(vol[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (n, n, hi - lo)), prm, slab)
-        extractor.emit(poff, coff)
+        extractor.emit(poff)
         m = extractor.download()
         assert np.array_equal(m.cells, whole.cells[coff:coff + n_c])
         assert np.array_equal(m.points.view(np.uint32), whole.points[poff:poff + n_p].view(np.uint32))
@@ -864,7 +864,7 @@ def test_marschner_lobb_bench_field_matches_oracle(pkg, oracle, extractor, n):
             slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
             n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi - lo)), prm, slab)
             assert not extractor.slab_info()[0]
-            res = extractor.emit(poff, 0)
+            res = extractor.emit(poff)
             m = extractor.download()
             pts.append(m.points)
             cells.append(m.cells)
@@ -906,7 +906,7 @@ def test_slab_halo_is_sized_by_the_parameters(pkg, oracle, extractor):
         lo, hi = max(a - halo, 0), min(b + halo, nz)
         slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
         n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi - lo), spacing), prm, slab)
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -1093,7 +1093,7 @@ def test_compiled_out_projection_branches_in_slabs(pkg, oracle, extractor, volum
         slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
         n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo)), prm,
                                    pkg._abi.Slab(nz, lo, a, b, 0, 0))
-        res = extractor.emit(poff, 0)
+        res = extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -1380,7 +1380,7 @@ def test_slabs_without_the_aliasing_quirk(pkg, extractor):
                                        pkg._abi.Slab(nz, lo, a, b, 0, 0))
             soft, _, _ = extractor.slab_info()
             assert not soft                                   # nothing to resolve with the quirk off
-            extractor.emit(poff, 0)
+            extractor.emit(poff)
             m = extractor.download()
             pts.append(m.points)
             cells.append(m.cells)
@@ -1411,7 +1411,7 @@ def test_slabs_under_a_tilted_direction_matrix(pkg, oracle, extractor):
         lo, hi = max(a - below, 0), min(b + above, nz)
         n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (nx, ny, hi - lo), **geo), prm,
                                    pkg._abi.Slab(nz, lo, a, b, 0, 0))
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         pts.append(m.points)
         cells.append(m.cells)
@@ -1480,7 +1480,7 @@ def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
         extractor.emit_points()
         extractor.emit_points()                              # harmless twice
         torch.cuda.synchronize()
-        extractor.emit(poff, 0)
+        extractor.emit(poff)
         m = extractor.download()
         assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
         pts.append(m.points)
