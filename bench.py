@@ -11,8 +11,10 @@ Workload: BASELINE.json configs[3], the 1024^3 float32 Marschner-Lobb volume, is
 triangles + vertex projection on (thr 0.002, step 0.25, relax 0.95, 50 steps).
 N>1, --scaling strong (the default: it is what the metric names, "1024^3 @1/2/4/8 GPU", and
 what configs[3] and [4] describe): that ONE volume is cut into N Z-slabs, every rank generates
-only its own slices; 8-slice halo exchanged over RCCL every step, one all-gather of the per-rank
-counts.  --scaling weak: each rank owns one 1024^3 block of a 1024x1024x(1024 N) volume (the
+only its own slices; per step a thin halo (3 + 3 slices: what a vertex needs where it starts, plus
+one) crosses the links over RCCL -- the rest of the 8-slice halo only when a walk really leaves it --
+and one all-gather of the per-rank rows that lands in device memory (the cell pass sums its id
+offset there: one host wait per step).  --full-halo / --host-offsets switch the two back.  --scaling weak: each rank owns one 1024^3 block of a 1024x1024x(1024 N) volume (the
 block repeats along z).  configs[4]: --workload noise --size 2048.
 
 Prints ONE JSON line on rank 0.
@@ -92,6 +94,41 @@ def measured_traffic(args, world, alg_bytes):
     return total * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
+def slab_probe(pkg, torch, ex, buf, n, dtype, prm, reps=20):
+    """What ONE rank of an 8-GPU strong-scaling run does per step, measured on this GPU (no exchange, no collective: its
+    device work and the host's share): slices [3n/8, 4n/8) of the resident volume as a THIN_HALO slab, through
+    cuberille_step_begin / _end with itself as the only rank.  wall - device is what the host adds per step."""
+    from midas_journal_740_amd.cuberille import minimum_halo
+    whole = pkg.make_desc(dtype, (n, n, n))
+    below, above = minimum_halo(whole, prm)
+    a, b = 3 * n // 8, 4 * n // 8
+    lo, hi = a - below - 1, b + above + 1
+    desc = pkg.make_desc(dtype, (n, n, hi - lo))
+    slab = pkg._abi.Slab(n, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO, None, None)
+    sub = buf[lo:hi]
+    wall = dev = 0.0
+    escaped = 0
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ptr, _ = ex.step_begin(sub.data_ptr(), desc, prm, slab)
+        res, done = ex.step_end(ptr, 1, 0)
+        t1 = time.perf_counter()
+        if not done:                               # escaped walks: the probe has no neighbours to ask; finish without them
+            escaped = ex.escaped_count()
+            ex.reproject_escaped(buf.data_ptr(), 0, n)
+            res = ex.emit(0)
+        elif i >= 2:
+            wall += t1 - t0
+            dev += res.ms_total
+    k = max(reps if not escaped else 0, 1)
+    return {"slices": [a, b], "halo": [below + 1, above + 1], "points": int(res.n_points), "cells": int(res.n_cells),
+            "wall_ms": round(wall / k * 1e3, 4), "device_ms": round(dev / k, 4),
+            "wall_minus_device_ms": round(wall / k * 1e3 - dev / k, 4), "host_waits_per_step": 1,
+            "halo_bytes_a_rank_would_receive": (below + above + 2) * n * n * int(np.dtype(dtype).itemsize),
+            "escaped_walks": int(escaped)}
+
+
 def cpu_baseline(pkg, torch, args, device):
     """The oracle restatement of the reference ("port"), timed on this box's host cores on a
     bounded sample of the same workload (the reference itself needs ITK)."""
@@ -138,6 +175,11 @@ def main():
     ap.add_argument("--gather-mesh", action="store_true",
                     help="N>1: after the timed region also concatenate the rank parts on rank 0 and report its time")
     ap.add_argument("--thr", type=float, default=None, help="override the projection threshold (experiments)")
+    ap.add_argument("--full-halo", action="store_true", help="N>1: exchange the whole projection-reach halo every step")
+    ap.add_argument("--host-offsets", action="store_true",
+                    help="N>1: the count all-gather through the host (two more host waits per step) instead of device-resident rows")
+    ap.add_argument("--no-slab-probe", action="store_true",
+                    help="N=1: skip the extra measurement of one 1/8 slab (what a rank of an 8-GPU run does per step)")
     args = ap.parse_args()
 
     import torch
@@ -185,7 +227,8 @@ def main():
     #  source slices between the ranks, two more small exchanges per step)
     prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
                           max_steps=50)
-    sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm)
+    sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
+                          device_offsets=not args.host_offsets)
     period = None if strong else n
     if args.workload == "sphere" and not strong:
         raise SystemExit("sphere workload: strong scaling or one GPU only")
@@ -208,12 +251,15 @@ def main():
     # the timed region carries the two event pairs every extraction has (the pass over the volume, the emit phase);
     # the per-stage events cost the stream about 8 us each and are switched on for a few extra extractions afterwards
     live = {"ms_pass": 0.0, "ms_total": 0.0}
+    host_side = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": 0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = sh.extract(buf, prm)
         for k in live:
             live[k] += getattr(res, k)
+        for k in host_side:
+            host_side[k] += int(sh.stats[k])
     barrier()
     dt = time.perf_counter() - t0
     acc = {k: 0.0 for k in stage_keys}
@@ -285,7 +331,9 @@ def main():
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": "%s %dx%dx%d %s iso=%g, triangles+projection (thr %g, step 0.25, relax 0.95, max 50)"
                                    % (args.workload, n, n, gnz, np.dtype(dtype).name, iso, thr),
-                       "per_gpu": "%dx%dx%d slab + %d-slice halo" % (n, n, sh.z1 - sh.z0, sh.halo if world > 1 else 0),
+                       "per_gpu": "%dx%dx%d slab + %s-slice halo%s" % (
+                           n, n, sh.z1 - sh.z0, ("%d+%d" % sh.thin) if sh.thin else str(sh.halo if world > 1 else 0),
+                           " (rest of the %d-slice halo on demand)" % sh.halo if sh.thin else ""),
                        "parallelism": "zslab%d" % world,
                        "points": n_points, "cells": n_cells,
                        "projection_iterations_rank0": int(res.proj_iterations)},
@@ -304,6 +352,13 @@ def main():
                                 "(cuberille_debug_set_option stage_timing); ms_total of the timed region: %.4f"
                                 % (STAGE_REPS, live["ms_total"] / args.steps),
         }
+        # what a step costs besides kernels (rank 0's view; per step, averaged over the timed region)
+        out["host_side"] = {"halo_bytes_per_rank": host_side["halo_bytes"] // args.steps,
+                            "host_syncs_per_step": round(host_side["host_syncs"] / args.steps, 2),
+                            "collectives_per_step": round(host_side["collectives"] / args.steps, 2),
+                            "escaped_walks_per_step": round(host_side["escaped"] / args.steps, 2),
+                            "steps_that_fetched_the_deep_halo": host_side["deep_halo_fetched"],
+                            "wall_minus_device_ms": round(dt / args.steps * 1e3 - live["ms_total"] / args.steps, 4)}
         out["roofline"]["note"] = ("largest kernel by time is the projection walk (%.0f %% of device time): f64 VALU-bound, "
                                    "neither an HBM nor an MFMA roofline applies to it" % (
                                        100.0 * stages["ms_project"] / stages["ms_total"]))
@@ -318,6 +373,8 @@ def main():
             out["d2h_mesh_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
             out["mesh_bytes"] = int(mesh.points.nbytes + mesh.cells.nbytes)
             del mesh
+        if world == 1 and not args.no_slab_probe and n >= 64:
+            out["slab_eighth_probe"] = slab_probe(pkg, torch, ex, buf, n, dtype, prm)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device)
         print(json.dumps(out), flush=True)

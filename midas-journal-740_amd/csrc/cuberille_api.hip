@@ -852,7 +852,12 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
   return CUBERILLE_OK;
 }
 
-int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank, cuberille_result *res) {
+}  // extern "C"
+
+namespace {
+
+// base: added to the offset summed from the rows (cuberille_extract_device on a slab: the caller's point_id_offset)
+int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank, u64 base, cuberille_result *res) {
   if (!c || !dev_rows || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? fail(c, CUBERILLE_ERR_ARGUMENT, "bad rows or rank") : CUBERILLE_ERR_ARGUMENT;
   if (c->stepMode == 0) return fail(c, CUBERILLE_ERR_STATE, "cuberille_step_end follows cuberille_step_begin");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -870,7 +875,7 @@ int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int 
   // by the cover values (blind) or by this rank's counts; a rank whose vertex phase did not run launches nothing.
   if (blind || c->pointsEmitted) {
     const u64 nQ = blind ? c->histQ + c->histQ / 4 + 4096 : c->tot.totQ - c->tot.Q0;
-    HIP_TRY(c, launch_emit_cells(c->w, c->g, c->prm.triangles, c->prm.q1, 0, nQ, nullptr, (const Totals *)dev_rows, n_ranks, rank,
+    HIP_TRY(c, launch_emit_cells(c->w, c->g, c->prm.triangles, c->prm.q1, base, nQ, nullptr, (const Totals *)dev_rows, n_ranks, rank,
                                  blind ? 1 : 0, s));
   }
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
@@ -881,7 +886,7 @@ int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int 
   HIP_TRY(c, hipMemcpyAsync(c->hostRows, dev_rows, (size_t)n_ranks * sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));                  // the one wait of the step
   u32 flags = 0;
-  u64 off = 0;
+  u64 off = base;
   for (int r = 0; r < n_ranks; r++) {
     flags |= c->hostRows[r].err;
     if (r < rank) off += c->hostRows[r].totV - c->hostRows[r].V0;
@@ -911,11 +916,26 @@ int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int 
   return finish_result(c, res);
 }
 
+}  // namespace
+
+extern "C" {
+
+int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank, cuberille_result *res) {
+  return step_end_impl(c, dev_rows, n_ranks, rank, 0, res);
+}
+
 int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
                              const cuberille_params *prm, const cuberille_slab *slab, cuberille_result *res) {
-  uint64_t np = 0, nc = 0;
-  int rc = cuberille_count(c, img, dev_voxels, prm, slab, &np, &nc);
+  // the one-wait step with this context as the only rank: the first extraction on a context reads its counts back
+  // before it sizes the emit, the following ones launch everything blindly from the sizes of the one before and wait
+  // once (every volume the reference ships is in the regime where the waits ARE the extraction time)
+  const void *row = nullptr;
+  size_t rowBytes = 0;
+  int rc = cuberille_step_begin(c, img, dev_voxels, prm, slab, &row, &rowBytes);
   if (rc) return rc;
+  rc = step_end_impl(c, row, 1, 0, slab ? slab->point_id_offset : 0, res);
+  if (rc != CUBERILLE_RETRY) return rc;
+  // counts beyond the guess, or a slab that needs its neighbours (quirk Q1, an escaped walk): the count stands
   return cuberille_emit(c, slab ? slab->point_id_offset : 0, res);
 }
 

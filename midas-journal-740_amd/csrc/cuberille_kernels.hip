@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
       if (r < a.rank) off += a.rows[r].totV - a.rows[r].V0;
     }
     if (flags) return;
-    a.pointOffset = off;
+    a.pointOffset += off;
   }
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
   int x, y, z, f;

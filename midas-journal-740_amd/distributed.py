@@ -332,10 +332,12 @@ class ShardedExtractor:
         if self.world == 1:
             if buf.is_cuda:
                 torch.cuda.current_stream().synchronize()
-            n_p, n_c = self.ex.count(buf.data_ptr(), self.desc, params, None)
-            self.counts = np.array([[n_p, n_c]], dtype=np.int64)
-            self.stats["host_syncs"] = 3 if buf.is_cuda else 0
-            return self.ex.emit(0)
+            # (cuberille_extract_device is the one-wait step with a single rank: from the second extraction on a context
+            #  on, everything is launched back to back and the host waits once)
+            res = self.ex.extract_device(buf.data_ptr(), self.desc, params, None)
+            self.counts = np.array([[int(res.n_points), int(res.n_cells)]], dtype=np.int64)
+            self.stats["host_syncs"] = 2 if buf.is_cuda else 0
+            return res
         need = max(required_halo(self.desc, params))
         if need > self.halo:
             raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "

@@ -149,7 +149,7 @@ int main()
   try
     {
     bool ok = true;
-    unsigned long p[6], c[6];
+    unsigned long p[9], c[9];
     ok &= run<unsigned char>("uchar", false, p[0], c[0]);
     ok &= run<short>("short", false, p[1], c[1]);
     ok &= run<unsigned short>("ushort", false, p[2], c[2]);
@@ -158,7 +158,11 @@ int main()
     ok &= run<double>("double", false, p[5], c[5]);
     // value >= 30 is the same set of voxels whether the field is truncated to an integer or not:
     // identical topology for every pixel type
-    for (int i = 1; i < 6; i++) ok &= (p[i] == p[0]) && (c[i] == c[0]);
+    // the 64-bit integer pixel types (LP64 long / unsigned long, long long)
+    ok &= run<long>("long", false, p[6], c[6]);
+    ok &= run<unsigned long>("ulong", false, p[7], c[7]);
+    ok &= run<long long>("longlong", false, p[8], c[8]);
+    for (int i = 1; i < 9; i++) ok &= (p[i] == p[0]) && (c[i] == c[0]);
     unsigned long pt, ct;
     ok &= run<float>("float-triangles", true, pt, ct);
     ok &= (pt == p[4]) && (ct == 2 * c[4]);

@@ -189,6 +189,7 @@ def _fake_worker(rank, world, port, scenario, out_dir):
 
         def count(ptr, desc, params, slab):
             calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
+            calls["thin"] = int(slab.flags)
             if scenario == "fail" and rank == 1:
                 raise pkg._abi.CuberilleError(pkg._abi.ERR_HALO, "synthetic failure")
             return 100 + rank, 7 * (rank + 1)
@@ -218,20 +219,31 @@ def _fake_worker(rank, world, port, scenario, out_dir):
 
         def recount(ptr):
             raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic recount failure")
+        def escaped_count():
+            return 5 if (scenario == "thin_escape" and rank == 1) else 0
+
+        def reproject_escaped(ptr, z_begin, nz_):
+            calls["reprojected"] = (z_begin, nz_)
         fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, emit_points=emit_points, result=None,
-                                     slice_bits_device=slice_bits_device, recount=recount)
+                                     slice_bits_device=slice_bits_device, recount=recount, escaped_count=escaped_count,
+                                     reproject_escaped=reproject_escaped)
         prm = pkg.make_params(0.5)
         # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused, or,
         #  "recount_fails", taken up to the consumer's recount, which fails: every rank must raise, none may hang)
         sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm,
-                                cross_slab_aliasing=scenario == "recount_fails")
+                                cross_slab_aliasing=scenario == "recount_fails", thin_halo=scenario.startswith("thin"))
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
-        buf = torch.zeros((sh.hi - sh.lo, ny, nx))
+        assert sh.thin == ((3, 3) if scenario.startswith("thin") else None)
+        # every slice of the buffer says which slice it is: the exchanges must bring exactly the halo they are asked for
+        buf = torch.full((sh.hi - sh.lo, ny, nx), -1.0)
+        for z in range(sh.z0, sh.z1):
+            buf[z - sh.lo] = float(z)
         err = ""
         try:
             sh.extract(buf, prm)
         except RuntimeError as e:
             err = str(e)
+        stats = dict(sh.stats)
         # a longer walk than the halo was sized for is refused before anything is exchanged
         too_far = ""
         try:
@@ -239,12 +251,22 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         except ValueError as e:
             too_far = str(e)
         assert "halo" in too_far
+        if scenario.startswith("thin") and not err:
+            have = sorted(int(buf[i, 0, 0]) for i in range(buf.shape[0]) if buf[i, 0, 0] >= 0)
+            deep = scenario == "thin_escape"
+            lo_, hi_ = (sh.lo, sh.hi) if deep else (sh.tlo, sh.thi)
+            assert have == list(range(lo_, hi_)), (have, lo_, hi_)
+            assert calls["thin"] == pkg._abi.SLAB_THIN_HALO and calls["slab"][1] == sh.tlo
+            assert stats["deep_halo_fetched"] == deep
+            assert calls.get("reprojected") == ((sh.lo, sh.hi - sh.lo) if (deep and rank == 1) else None)
+            slice_bytes = nx * ny * 4
+            assert stats["halo_bytes"] == ((sh.hi - sh.lo) - (sh.z1 - sh.z0) if deep else (sh.thi - sh.tlo) - (sh.z1 - sh.z0)) * slice_bytes
         np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([err, repr(calls.get("offsets")), repr(calls.get("slab"))]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails"])
+@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails", "thin", "thin_escape"])
 def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
     (nobody is left waiting in the all-gather); quirk Q1 crossing the slab boundary is refused exactly when a rank
@@ -252,10 +274,13 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     port = _free_port()
     mp.spawn(_fake_worker, args=(2, port, scenario, str(tmp_path)), nprocs=2, join=True)
     rows = [np.load(str(tmp_path / ("r%d.npy" % r))) for r in range(2)]
-    if scenario in ("ok", "alias_nothing_below"):
+    if scenario in ("ok", "alias_nothing_below", "thin", "thin_escape"):
         assert rows[0][0] == "" and rows[1][0] == ""
         assert rows[0][1] == "(0,)" and rows[1][1] == "(100,)"
-        assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 12, 20, 40)"
+        if scenario.startswith("thin"):                    # 3 + 3 slices around the owned range, flagged as a thin slab
+            assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 17, 20, 40)"
+        else:
+            assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 12, 20, 40)"
     elif scenario == "fail":
         assert all("cuberille_count failed on rank(s) [1]" in r[0] for r in rows)
     elif scenario == "recount_fails":

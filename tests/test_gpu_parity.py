@@ -279,7 +279,7 @@ def test_reference_driver_unchanged(pkg, extractor, oracle, volumes, ctest_cases
     assert r.returncode != 0 and "Expected mesh with 9 points" in r.stderr
 
 
-def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0.24):
+def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0.24, mode="sync", relax=0.95):
     import os
     import sys
     import torch
@@ -296,13 +296,30 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
         vol = pkg.read_mha(os.path.join(GOLDEN, "data", name))
         nx, ny, nz = vol.dims
         ex = pkg.Extractor(0)
-        prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=0.95, max_steps=100)
-        sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm)
+        prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=relax, max_steps=100)
+        # mode: "sync" the host in the loop; "step" device-resident offsets (cuberille_step_begin / _end);
+        # "thin" / "step_thin": the same with the thin halo (walks that leave it are put aside and walked again)
+        sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm,
+                              thin_halo="thin" in mode, device_offsets=mode.startswith("step"))
         sh.force_event_path = bool(event_path)
-        assert sh.halo == (8 if step == 0.24 else 13)
+        if relax == 0.95:
+            assert sh.halo == (8 if step == 0.24 else 13)
+        if "thin" in mode:
+            assert sh.thin == (3, 3)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()   # owned slices only
-        sh.extract(buf, prm)
+        first = sh.extract(buf, prm)
+        stats = [dict(sh.stats)]
+        if mode != "sync":
+            # a second step on the same contexts: the blind launches sized from the first one ("step"), the halo slices
+            # wiped so that the exchange has to bring them again
+            keep = (int(first.n_points), int(first.n_cells), int(first.proj_iterations))
+            buf[:sh.z0 - sh.lo].zero_()
+            buf[sh.z1 - sh.lo:].zero_()
+            second = sh.extract(buf, prm)
+            assert (int(second.n_points), int(second.n_cells), int(second.proj_iterations)) == keep
+            stats.append(dict(sh.stats))
+        np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([repr(stats)]))
         m = ex.download()
         np.save(os.path.join(out_dir, "p%d.npy" % rank), m.points)
         np.save(os.path.join(out_dir, "c%d.npy" % rank), m.cells)
@@ -318,14 +335,20 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,event_path,step", [(2, False, 0.24), (3, False, 0.24), (2, True, 0.24), (4, False, 0.5)])
-def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step):
+@pytest.mark.parametrize("world,event_path,step,mode,relax", [
+    (2, False, 0.24, "sync", 0.95), (3, False, 0.24, "step", 0.95), (2, True, 0.24, "step", 0.95), (4, False, 0.5, "sync", 0.95),
+    (3, False, 0.24, "thin", 0.95), (2, True, 0.24, "step_thin", 0.95), (4, False, 0.5, "step_thin", 0.95),
+    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0)])
+def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step, mode, relax):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
     the concatenation of the rank meshes must be the oracle's mesh of the whole volume.  event_path: the
     non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo).  Four ranks on the
     40 slices of silicium with a step of 0.5: 10-slice slabs under a 13-slice halo, so every rank receives from ranks
-    beyond its neighbours (four ranks, not more: the box allows six processes on its GPU, this one included)."""
+    beyond its neighbours (four ranks, not more: the box allows six processes on its GPU, this one included).
+    mode "step": the step without a host round trip between count and emit, twice on the same contexts (sized by a host
+    read, then blind).  "thin": only 3 + 3 halo slices cross per step; with step 0.6 and no relaxation (102 steps of 0.6:
+    walks cross whole slabs) many walks leave them, every rank fetches the rest of the halo and walks those again."""
     import socket
     import torch.multiprocessing as mp
     name, iso = "silicium.mha", 85
@@ -333,11 +356,19 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path, step), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path, step, mode, relax), nprocs=world, join=True)
     pts = np.concatenate([np.load(str(tmp_path / ("p%d.npy" % r))) for r in range(world)])
     cells = np.concatenate([np.load(str(tmp_path / ("c%d.npy" % r))) for r in range(world)])
-    ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=step, relax=0.95,
+    ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=step, relax=relax,
                      max_steps=100)
+    stats = [eval(str(np.load(str(tmp_path / ("stats%d.npy" % r)))[0])) for r in range(world)]
+    if "thin" in mode:
+        # 3 + 3 slices instead of the full halo -- unless walks left them (relax 1.0: they do)
+        assert all(st[0]["deep_halo_fetched"] == (relax == 1.0) for st in stats), stats
+        if relax == 1.0:
+            assert sum(st[0]["escaped"] for st in stats) > 0
+    if mode.startswith("step"):
+        assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 2) for st in stats), stats
 
     class M:
         pass
@@ -1487,3 +1518,288 @@ def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
         cells.append(m.cells)
         poff += n_p
     assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+# ---- round 3: every instantiation of the large-volume sweep, 64-bit pixels, counters, thin halo, one-wait step -----------
+
+@pytest.mark.parametrize("dtype,shape", [
+    (np.uint16, (512, 512, 512)), (np.int16, (512, 512, 512)), (np.int8, (1024, 512, 512)), (np.uint8, (1024, 512, 512)),
+    (np.uint32, (320, 512, 512)), (np.int32, (320, 512, 512)), (np.float64, (256, 512, 512)),
+    (np.int64, (128, 512, 512)), (np.uint64, (128, 512, 512))])
+def test_span_sweep_every_pixel_type(pkg, extractor, dtype, shape):
+    """k_classify_span<T> -- the sweep every launch of 256 MiB or more takes -- for every pixel type the library is
+    instantiated for (round 2 only ever ran it for float and uint8; the 2-voxels-per-lane group OR of the 8-byte types
+    ran nowhere): packed inside bits equal a torch threshold, counts equal the closed form (txx:139-141, 164-173)."""
+    import torch
+    nz, ny, nx = shape
+    tdt = {np.uint16: torch.int32, np.int16: torch.int16, np.int8: torch.int8, np.uint8: torch.uint8, np.uint32: torch.int64,
+           np.int32: torch.int32, np.float64: torch.float64, np.int64: torch.int64, np.uint64: torch.int64}[dtype]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # smooth blobs + noise, so that the surface is neither empty nor everything
+    z = torch.arange(nz, device="cuda", dtype=torch.float32)[:, None, None]
+    y = torch.arange(ny, device="cuda", dtype=torch.float32)[None, :, None]
+    x = torch.arange(nx, device="cuda", dtype=torch.float32)[None, None, :]
+    field = torch.sin(z * 0.11) + torch.sin(y * 0.07 + 1.0) + torch.sin(x * 0.05 + 2.0)
+    field += (torch.rand(shape, device="cuda", generator=g) - 0.5) * 0.02
+    info = np.iinfo(dtype) if np.dtype(dtype).kind in "iu" else None
+    if info is not None:
+        lo, hi = (float(info.min) * 0.9, float(info.max) * 0.9) if np.dtype(dtype).itemsize < 8 else (-2.0 ** 40, 2.0 ** 40)
+        if info.min == 0:
+            lo = 0.0
+        vol = ((field + 3.0) / 6.0 * (hi - lo) + lo).to(torch.float64).round().to(tdt)
+        iso = int(round((lo + hi) / 2.0))
+    else:
+        vol = field.to(tdt)
+        iso = 0.125
+    del field
+    # (the unsigned types as the signed tensor of the same width: a narrowing torch conversion wraps like a C cast, so the
+    #  bits are the unsigned value's)
+    dev = vol.to({np.uint16: torch.int16, np.uint32: torch.int32}[dtype]) if dtype in (np.uint16, np.uint32) else vol
+    assert dev.element_size() == np.dtype(dtype).itemsize and dev.numel() * dev.element_size() >= (256 << 20)
+    torch.cuda.synchronize()
+    inside = vol >= iso
+    want_pts, want_quads = _closed_form_counts_torch(inside)
+    assert 1000 < want_quads
+    res = extractor.extract_device(dev.data_ptr(), pkg.make_desc(dtype, (nx, ny, nz)), pkg.make_params(iso, triangles=False, project=False))
+    assert (int(res.n_points), int(res.n_cells)) == (want_pts, want_quads)
+    words = torch.from_numpy(extractor.debug_bits((nx, ny, nz)).view(np.int64)).cuda()
+    shifts = torch.arange(64, device="cuda", dtype=torch.int64)
+    for z0 in range(0, nz, 32):
+        bits = ((words[z0:z0 + 32, :, :, None] >> shifts) & 1).bool().reshape(-1, ny, nx)
+        assert torch.equal(bits, inside[z0:z0 + 32]), "packed bits differ from the threshold in slices %d.." % z0
+    del vol, dev, inside, words
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32, np.float64])
+def test_whole_word_rows_at_every_pointer_alignment(pkg, oracle, extractor, dtype):
+    """Rows of whole 64-voxel words behind a device pointer that is NOT 16-byte aligned leave the vector sweep for the
+    flat-stream path (or, without its scratch, the one-voxel-per-lane kernel): every byte skew, same mesh."""
+    import torch
+    rng = np.random.default_rng(12)
+    item = np.dtype(dtype).itemsize
+    prm = pkg.make_params(100, triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=20)
+    for shape in [(3, 5, 64), (2, 3, 128), (4, 2, 192)]:
+        vol = (rng.random(shape) * 200).astype(dtype)
+        want = oracle.run(vol, 100, triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=20)
+        nz, ny, nx = shape
+        desc = pkg.make_desc(dtype, (nx, ny, nz))
+        raw = torch.zeros(vol.nbytes + 64, dtype=torch.uint8, device="cuda")
+        for variant in (0, 1):
+            extractor.debug_option("no_stream_classify", variant)
+            for skew in range(0, 16, item):
+                raw.zero_()
+                raw[skew:skew + vol.nbytes] = torch.from_numpy(vol.view(np.uint8).reshape(-1)).cuda()
+                torch.cuda.synchronize()
+                extractor.extract_device(raw.data_ptr() + skew, desc, prm)
+                assert_same_mesh(extractor.download(), want)
+        extractor.debug_option("defaults", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64])
+def test_64bit_integer_pixels_match_oracle(pkg, oracle, extractor, dtype):
+    """itk::Image<long,3> / <unsigned long,3> (h:150 takes any InputPixelType): compared in the pixel type, through
+    (float) into the gradient taps and (double) into the interpolation -- small values (the same mesh as int32), values
+    past 2^24 and 2^53 where both conversions round, an iso value a double cannot hold, rows of every kind."""
+    rng = np.random.default_rng(21)
+    kw = dict(triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=30)
+    for shape in [(6, 7, 9), (5, 4, 64), (4, 3, 130)]:
+        small = rng.integers(0, 200, size=shape).astype(dtype)
+        a = run_gpu(pkg, extractor, pkg.Volume(small), 100, **kw)
+        assert_same_mesh(a, oracle.run(small, 100, **kw))
+        assert_same_mesh(a, oracle.run(small.astype(np.int32), 100, **kw))
+        # magnitudes where (float)pixel and (double)pixel round: a smooth field scaled to 2^55, low bits noisy
+        zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+        f = np.sin(zz * 0.9) + np.sin(yy * 0.7 + 1.0) + np.sin(xx * 0.3 + 2.0)
+        big = ((f + 3.0) * 2.0 ** 55).astype(dtype) + rng.integers(0, 1 << 20, size=shape).astype(dtype)
+        iso = (3 << 55) + 12345677                               # not a double
+        assert float(iso) != iso
+        kwb = dict(kw, threshold=2.0 ** 50)
+        m = run_gpu(pkg, extractor, pkg.Volume(big), iso, **kwb)
+        ref = oracle.run(big, iso, **kwb)
+        assert len(ref.points) > 20
+        assert_same_mesh(m, ref)
+    if dtype == np.uint64:
+        top = (rng.integers(0, 200, size=(5, 6, 70)).astype(np.uint64) << np.uint64(56)) + np.uint64(99)   # above 2^63
+        iso = (100 << 56) + 5
+        m = run_gpu(pkg, extractor, pkg.Volume(top), iso, **dict(kw, threshold=2.0 ** 58))
+        assert_same_mesh(m, oracle.run(top, iso, **dict(kw, threshold=2.0 ** 58)))
+    else:
+        neg = rng.integers(-(1 << 40), 1 << 40, size=(5, 6, 70)).astype(np.int64)
+        m = run_gpu(pkg, extractor, pkg.Volume(neg), -12345, **dict(kw, threshold=2.0 ** 30))
+        assert_same_mesh(m, oracle.run(neg, -12345, **dict(kw, threshold=2.0 ** 30)))
+
+
+def test_termination_counters_match_oracle(pkg, oracle, extractor, volumes):
+    """cuberille_result::proj_stop_threshold / proj_stop_steps = the reference's DEBUG_PRINT counters (h:336-338;
+    txx:457-459, 470-472) as the oracle counts them, for all three projection branches and in slabs."""
+    for name, iso, max_steps in [("nucleon.mha", 140, 100), ("marschnerlobb.mha", 55, 200), ("fuel.mha", 15, 5)]:
+        vol = volumes(name)
+        for variant in (0, 1, 2):
+            kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=max_steps)
+            ref = oracle.run(vol.voxels, iso, variant=variant, **kw)
+            res = extractor.extract_host(vol, pkg.make_params(iso, variant=variant, **kw))
+            got = (int(res.proj_iterations), int(res.proj_stop_threshold), int(res.proj_stop_steps))
+            assert got == (ref.info["proj_iterations"], ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"]), (name, variant)
+            if variant == 0:
+                assert got[1] + got[2] == len(ref.points)
+    # without projection nothing is counted; in slabs the owned vertices only
+    res = extractor.extract_host(volumes("fuel.mha"), pkg.make_params(15, project=False))
+    assert (int(res.proj_stop_threshold), int(res.proj_stop_steps)) == (0, 0)
+    import torch
+    vol = volumes("marschnerlobb.mha")
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=200)
+    ref = oracle.run(vol.voxels, 55, **kw)
+    nx, ny, nz = vol.dims
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    prm = pkg.make_params(55, **kw)
+    thr = steps = poff = 0
+    for a, b in [(0, 17), (17, 30), (30, nz)]:
+        lo, hi = max(a - 8, 0), min(b + 8, nz)
+        n_p, _ = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, hi - lo)), prm, pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        r = extractor.emit(poff)
+        thr += int(r.proj_stop_threshold)
+        steps += int(r.proj_stop_steps)
+        poff += n_p
+    assert (thr, steps) == (ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"])
+
+
+def test_thin_halo_slabs_equal_the_one_shot_mesh(pkg, oracle, extractor, volumes):
+    """CUBERILLE_SLAB_THIN_HALO in one process: slabs that hold 3 + 3 halo slices (cuberille_minimum_halo + 1) instead
+    of the 8 the walk can reach give the oracle's mesh bit for bit -- with no walk leaving them at the driver's
+    parameters, and, when walks are forced out (step 0.6, no relaxation), through the escape list and
+    cuberille_reproject_escaped on the full buffer; cuberille_emit refuses while walks wait."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    desc_all = pkg.make_desc(np.uint8, (nx, ny, nz))
+    for step, relax, expect_escapes in [(0.24, 0.95, False), (0.6, 1.0, True)]:
+        kw = dict(triangles=1, project=1, threshold=0.2, step=step, relax=relax, max_steps=100)
+        prm = pkg.make_params(85, **kw)
+        ref = oracle.run(vol.voxels, 85, **kw)
+        assert pkg.cuberille.minimum_halo(desc_all, prm) == (2, 2)
+        assert pkg.cuberille.minimum_halo(desc_all, pkg.make_params(85, project=False)) == (2, 1)
+        deep = max(pkg.cuberille.required_halo(desc_all, prm))
+        pts, cells, poff, escaped, iters = [], [], 0, 0, 0
+        for a, b in [(0, 9), (9, 10), (10, 27), (27, nz)]:
+            lo, hi = max(a - 3, 0), min(b + 3, nz)
+            slab = pkg._abi.Slab(nz, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO)
+            n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, hi - lo)), prm, slab)
+            extractor.emit_points()
+            n_esc = extractor.escaped_count()
+            escaped += n_esc
+            if n_esc:
+                with pytest.raises(pkg._abi.CuberilleError) as e:
+                    extractor.emit(poff)
+                assert e.value.code == pkg._abi.ERR_HALO
+                with pytest.raises(pkg._abi.CuberilleError) as e:      # a buffer that is still too thin is refused
+                    extractor.reproject_escaped(dev[lo:hi].data_ptr(), lo, hi - lo)
+                assert e.value.code == pkg._abi.ERR_HALO
+                dlo, dhi = max(a - deep, 0), min(b + deep, nz)
+                extractor.reproject_escaped(dev[dlo:dhi].data_ptr(), dlo, dhi - dlo)
+            r = extractor.emit(poff)
+            assert int(r.n_escaped) == 0
+            iters += int(r.proj_iterations)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+
+        class M:
+            pass
+        m = M()
+        m.points, m.cells = np.concatenate(pts), np.concatenate(cells)
+        assert_same_mesh(m, ref)
+        assert iters == ref.info["proj_iterations"]
+        assert (escaped > 0) == expect_escapes, escaped
+    # a thin slab must still hold the topology's slices, and is not offered with the compiled-out projection branches
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.count(dev[9:21].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, 12)), prm, pkg._abi.Slab(nz, 9, 10, 20, 0, pkg._abi.SLAB_THIN_HALO))
+    assert e.value.code == pkg._abi.ERR_HALO
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.count(dev[7:23].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, 16)), pkg.make_params(85, variant=1, **kw),
+                        pkg._abi.Slab(nz, 7, 10, 20, 0, pkg._abi.SLAB_THIN_HALO))
+    assert e.value.code == pkg._abi.ERR_ARGUMENT
+
+
+def test_one_wait_step_on_one_rank(pkg, oracle, volumes):
+    """cuberille_step_begin / cuberille_step_end with a single rank (the row is its own gather): the first extraction on
+    a context sizes its launches by a host read, the following ones blindly from the one before; a volume whose counts
+    exceed that guess comes back with CUBERILLE_RETRY, the synchronous calls finish it, and the next step is blind again."""
+    import torch
+    ex = pkg.Extractor(0)
+    try:
+        kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+        refs = {}
+        for round_ in range(2):
+            for name, iso in [("fuel.mha", 15), ("fuel.mha", 15), ("blob0.mha", 200), ("hydrogenAtom.mha", 15), ("nucleon.mha", 140)]:
+                vol = volumes(name)
+                nx, ny, nz = vol.dims
+                dev = torch.from_numpy(vol.voxels).cuda()
+                torch.cuda.synchronize()
+                desc, prm = pkg.make_desc(np.uint8, (nx, ny, nz)), pkg.make_params(iso, **kw)
+                if name not in refs:
+                    refs[name] = oracle.run(vol.voxels, iso, **kw)
+                ref = refs[name]
+                ptr, nbytes = ex.step_begin(dev.data_ptr(), desc, prm)
+                assert nbytes % 8 == 0
+                res, done = ex.step_end(ptr, 1, 0)
+                assert (int(res.n_points), int(res.n_cells)) == (len(ref.points), len(ref.cells))
+                if not done:
+                    # hydrogenAtom after blob0 (8 points): far beyond the guess
+                    assert name == "hydrogenAtom.mha"
+                    res = ex.emit(0)
+                assert_same_mesh(ex.download(), ref)
+                assert int(res.proj_iterations) == ref.info["proj_iterations"]
+                assert int(res.proj_stop_steps) == ref.info["proj_stop_steps"]
+                del dev
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("triangles,threads", [(0, 1), (1, 1), (1, 4)])
+def test_filter_with_a_nonlinear_interpolator(oracle, tmp_path, triangles, threads):
+    """The whole drop-in filter with a TInterpolator that is not the linear one (h:110; B-spline in the reference's
+    driver, Testing/CuberilleTest01.cxx:73-75): topology and start points from the GPU, the walk on the host through the
+    user's Evaluate() -- here a blend with a second, smoothed image.  Points equal a Python restatement of txx:439-474
+    over the oracle's pinned primitives, quads equal the oracle's, triangles follow txx:286-321 on those points; four
+    host threads (opt-in) give the same mesh."""
+    from restate import blend_field, blend_value, py_default_walk, split_quads
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "host_walk")
+    vol, smooth = blend_field()
+    n = vol.shape[0]
+    kw = dict(threshold=0.02, step=0.25, relax=0.95, max_steps=30)
+    flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+    vol.tofile(str(tmp_path / "v.raw"))
+    smooth.tofile(str(tmp_path / "s.raw"))
+    r = subprocess.run([exe, "filter", str(tmp_path / "v.raw"), str(tmp_path / "s.raw"), str(n), "0.0", "0.02", "0.25", "0.95", "30",
+                        str(tmp_path / "p.raw"), str(tmp_path / "c.raw"), str(triangles), str(threads)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    pts = np.fromfile(str(tmp_path / "p.raw"), dtype=np.float32).reshape(-1, 3)
+    cells = np.fromfile(str(tmp_path / "c.raw"), dtype=np.uint64).reshape(-1, 3 if triangles else 4)
+    assert pts.shape == flat.points.shape
+    value = blend_value(oracle, vol, smooth)
+    want = np.array([py_default_walk(oracle, vol, value, 0.0, v, kw["threshold"], kw["step"], kw["relax"], kw["max_steps"])[0]
+                     for v in flat.points], dtype=np.float32)
+    assert np.array_equal(want.view(np.uint32), pts.view(np.uint32))
+    if triangles:
+        assert np.array_equal(cells, split_quads(want, flat.cells.astype(np.int64)).astype(np.uint64))
+    else:
+        assert np.array_equal(cells, flat.cells)
+
+
+def test_throwing_interpolator_leaves_through_update(tmp_path):
+    """An exception thrown by the user's Evaluate() -- on the calling thread or inside one of the opt-in worker threads --
+    comes out of Update() as an exception (round-2 advisor finding: a worker's exception used to end in std::terminate)."""
+    from restate import blend_field
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "host_walk")
+    vol, smooth = blend_field(20)
+    vol.tofile(str(tmp_path / "v.raw"))
+    smooth.tofile(str(tmp_path / "s.raw"))
+    for threads in (1, 4):
+        r = subprocess.run([exe, "throw", str(tmp_path / "v.raw"), str(tmp_path / "s.raw"), "20", "0.0", str(threads)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "caught: interpolator gave up" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -289,3 +289,45 @@ def test_c_abi_from_plain_c(pkg):
     if not _has_gpu(pkg):
         r = subprocess.run([exe, "nothing.raw", "4", "4", "4", "u8", "1", "out.vtk"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 2 and "no gfx950 device" in r.stderr, (r.returncode, r.stderr)
+
+
+def _host_walk_exe():
+    import subprocess
+    exe = os.path.join(ROOT, "midas-journal-740_amd", "itk", "build", "host_walk")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "midas-journal-740_amd", "itk"), "build/host_walk"])
+    return exe
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_host_walk_through_a_nonlinear_interpolator(pkg, oracle, tmp_path, threads):
+    """The drop-in filter's host walk (itkCuberilleImageToMeshFilter.txx: HostGradient + HostWalk, taken for any
+    TInterpolator the kernels do not implement, h:110 / txx:455) through an interpolator whose Evaluate() is NOT the
+    linear one -- it blends the image with a second, smoothed image: every vertex lands, bit for bit, where a Python
+    restatement of txx:439-474 over the oracle's pinned primitives puts it.  Needs no GPU: the start points are the
+    oracle's unprojected vertices.  threads 3: the opt-in threaded form gives the same points."""
+    import subprocess
+    from restate import blend_field, blend_value, py_default_walk
+    vol, smooth = blend_field()
+    n = vol.shape[0]
+    kw = dict(threshold=0.02, step=0.25, relax=0.95, max_steps=30)
+    flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+    assert len(flat.points) > 300
+    vol.tofile(str(tmp_path / "v.raw"))
+    smooth.tofile(str(tmp_path / "s.raw"))
+    flat.points.tofile(str(tmp_path / "start.raw"))
+    r = subprocess.run([_host_walk_exe(), "walk", str(tmp_path / "v.raw"), str(tmp_path / "s.raw"), str(n), "0.0", "0.02", "0.25",
+                        "0.95", "30", str(tmp_path / "start.raw"), str(len(flat.points)), str(tmp_path / "out.raw"), str(threads)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    got = np.fromfile(str(tmp_path / "out.raw"), dtype=np.float32).reshape(-1, 3)
+    value = blend_value(oracle, vol, smooth)
+    moved = 0
+    for i, v in enumerate(flat.points):
+        want, _ = py_default_walk(oracle, vol, value, 0.0, v, kw["threshold"], kw["step"], kw["relax"], kw["max_steps"])
+        assert np.array_equal(np.asarray(want, dtype=np.float32).view(np.uint32), got[i].view(np.uint32)), i
+        moved += int(not np.array_equal(got[i], v))
+    assert moved > len(flat.points) // 2
+    # ... and it is not the linear interpolator's walk
+    lin = oracle.run(vol, 0.0, triangles=False, project=True, **kw)
+    assert not np.array_equal(lin.points, got)

@@ -189,37 +189,7 @@ def test_oracle_reproduces_bench_field_digests(pkg, oracle):
 # checked against a second, independent restatement: the control flow below in plain Python floats (IEEE double, like
 # the reference's arithmetic) over the two primitives the contract tests above pin (I5 interpolation, I6 gradient).
 
-def _f32(v):
-    return float(np.float32(v))
-
-
-def _py_normal(oracle, vol, p):
-    n = vol.shape[::-1]
-    lo, hi, d = [], [], []
-    for k in range(3):
-        b = np.floor(p[k])
-        d.append(p[k] - b)
-        lo.append(int(min(max(b, 0), n[k] - 1)))
-        hi.append(int(min(max(b + 1, 0), n[k] - 1)))
-    acc, total = [0.0, 0.0, 0.0], 0.0
-    for counter in range(8):
-        overlap, ni = 1.0, []
-        for k in range(3):
-            if counter & (1 << k):
-                ni.append(hi[k]); overlap *= d[k]
-            else:
-                ni.append(lo[k]); overlap *= 1.0 - d[k]
-        if overlap:
-            g = oracle.gradient_at_index(vol, tuple(ni))
-            for k in range(3):
-                acc[k] += overlap * float(g[k])
-            total += overlap
-        if total == 1.0:
-            break
-    nrm = [_f32(a) for a in acc]
-    norm = float(np.sqrt(np.float64(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2])))
-    with np.errstate(all="ignore"):
-        return [_f32(np.float64(v) / np.float64(norm)) for v in nrm]
+from restate import f32 as _f32, py_normal as _py_normal, py_default_walk as _py_default_walk  # noqa: E402
 
 
 def _py_advanced(oracle, vol, iso, v, thr, step, relax, max_steps):
@@ -306,3 +276,19 @@ def test_compiled_out_projection_branches_properties(oracle):
     # no sample at all (max_steps < 4): the vertex stays where it is
     none = oracle.run(sdf, 0.0, project=True, variant=2, **dict(kw, max_steps=3))
     assert np.array_equal(none.points.view(np.uint32), flat.points.view(np.uint32))
+
+
+def test_default_walk_restatement_matches_the_oracle(oracle):
+    """tests/restate.py:py_default_walk (txx:439-474 in Python over the pinned primitives) against the oracle's own
+    default branch: the restatement the host-walk tests of the drop-in filter lean on is itself held to the oracle."""
+    vol = _small_field()
+    kw = dict(threshold=0.01, step=0.3, relax=0.9, max_steps=14)
+    flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+    got = oracle.run(vol, 0.0, triangles=False, project=True, **kw)
+    passes = 0
+    for i, v in enumerate(flat.points):
+        want, n = _py_default_walk(oracle, vol, lambda p: oracle.interpolate(vol, p), 0.0, v, kw["threshold"], kw["step"],
+                                   kw["relax"], kw["max_steps"])
+        passes += n
+        assert np.array_equal(np.asarray(want, dtype=np.float32).view(np.uint32), got.points[i].view(np.uint32)), i
+    assert got.info["proj_iterations"] == passes
