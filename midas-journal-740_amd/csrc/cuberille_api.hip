@@ -752,6 +752,8 @@ int cuberille_reproject_escaped(cuberille_ctx *c, const void *dev_voxels, int64_
   Workspace w = c->w;
   w.vox = dev_voxels;
   HIP_TRY(c, launch_project(c->pixel_type, w, deep, c->geo, c->prm, n, c->tot.V0, c->tune, 2, 0, c->stream));
+  // nobody waits any more (the list's length travelled by value): the device-side counter starts over
+  HIP_TRY(c, hipMemsetAsync(&c->w.totals->nEscaped, 0, sizeof(u32), c->stream));
   c->tot.nEscaped = 0;
   return CUBERILLE_OK;
 }

@@ -1551,6 +1551,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   unsigned myIters = 0;
   u32 stopStepsW = 0;                              // wave-uniform: owned walks of this wave that ran out of steps
   bool escapedW = false;                           // wave-uniform: some walk of this wave left the buffer (MODE 1)
+  // (both are only ever updated where the whole wave passes, from lane flags set inside the divergent walk)
   bool active = false;
   u64 idx = 0;
   float vertex[3] = {0.f, 0.f, 0.f};
@@ -1586,12 +1587,12 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       next += take < remaining ? take : remaining;
     }
     if (!__ballot(active)) break;
+    bool bySteps = false, escaped = false;
     if (active) {
       bool done = false;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
       make_cell(geo, unitP2I, n, p, c);
-      bool escaped = false;
       if (MODE == 1 && (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2])) {
         // global slices the cell and its gradient ring read, against the buffer
         const int zlo = max(c.lo[2] - 1, 0), zhi = min(c.hi[2] + 1, n[2] - 1);
@@ -1602,7 +1603,6 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           else atomicOr(&tot->err, (u32)ERRF_ESCAPE_OVERFLOW);
           active = false;                            // the point keeps its start position
         }
-        escapedW = escapedW || __ballot(escaped) != 0ull;
       }
       if (!escaped) {
       if (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2]) {
@@ -1714,8 +1714,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
         step *= prm.relax;                                                    // txx:468
         done = numberOfSteps++ > prm.max_steps;                               // txx:469
-        // (txx:470-472's counter; a scalar per wave -- the walks that end within the threshold are the rest)
-        stopStepsW += (u32)__popcll(__ballot(done && idx >= nGhost));
+        bySteps = done && idx >= nGhost;                                      // txx:470-472's counter
       }
       if (done) {
         points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
@@ -1724,6 +1723,9 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       }
       }
     }
+    // (a scalar per wave; the walks that end within the threshold are the rest)
+    stopStepsW += (u32)__popcll(__ballot(bySteps));
+    if (MODE == 1) escapedW = escapedW || __ballot(escaped) != 0ull;
   }
   // one atomic per wave for the iteration statistic
   unsigned sum = myIters;

@@ -84,7 +84,7 @@ def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, rel
     # (the 64-bit integer pixel types take the iso value as an integer: a double cannot hold it past 2^53)
     iso_int = 0
     try:
-        if float(iso) == int(iso):
+        if isinstance(iso, (int, np.integer)) or float(iso) == int(iso):
             iso_int = int(iso)
     except (OverflowError, ValueError):
         pass

@@ -104,7 +104,7 @@ int main(int argc, char **argv)
     filter->SetIsoSurfaceValue((float)std::atof(argv[5]));
     if (!std::strcmp(mode, "throw"))
       {
-      interp->throwAfter = 5000;
+      interp->throwAfter = 200;
       filter->SetHostWalkThreads((unsigned int)std::atoi(argv[6]));
       try { filter->Update(); }
       catch (std::exception &e) { std::cout << "caught: " << e.what() << std::endl; return 0; }

@@ -96,7 +96,7 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     img, keep = _image(vol, spacing, origin, direction)
     iso_int = 0
     try:
-        if float(iso) == int(iso):
+        if isinstance(iso, (int, np.integer)) or float(iso) == int(iso):
             iso_int = int(iso)
     except (OverflowError, ValueError):
         pass
