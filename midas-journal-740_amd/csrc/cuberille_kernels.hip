@@ -66,10 +66,36 @@ struct Vec16 {
   union { uint4 raw; T v[N]; };
 };
 
+// 3-input boolean function on the gfx950 v_bitop3_b32 (truth table TT: bit (a<<2 | b<<1 | c))
+template <int TT>
+__device__ __forceinline__ u32 bop3_32(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+
 // inside-bits of the 16/sizeof(T) pixels of one 16-byte load: bit j = !(pixel j < iso)
-template <class T>
+template <class T, bool SWAR_OLD = false>
 __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
-  if constexpr (sizeof(T) == 1) {
+  if constexpr (sizeof(T) == 1 && !SWAR_OLD) {
+    // 1-byte pixels, SWAR on the packed dwords.  Per byte, unsigned x >= t: with xl, tl the low 7 bits, bit 7 of
+    // ((xl | 0x80) - tl) says xl >= tl (no borrow crosses bytes), and x >= t is (x7 | that) when t < 128, (x7 & that)
+    // when t >= 128; signed pixels are biased by 0x80 first.  Three instructions per dword on v_bitop3 ((x & 0x7f..) |
+    // 0x80.., the subtraction, (x op d) & 0x80..), and the four bit-7s of a dword are gathered by ONE v_dot4_u32_u8
+    // against the byte weights 1, 2, 4, 8 (16 .. 128 for the odd dwords), accumulating as it goes: a sum of 0x80 * weight
+    // per inside voxel, i.e. the eight bits of two dwords shifted left by 7.  (The 32-bit multiply that used to gather
+    // them issues at a quarter of the rate: 2048^3 uint8 went from 1.69 ms to the figure in DESIGN.md.)
+    const u32 bias = std::is_signed<T>::value ? 0x80808080u : 0u;
+    const u32 t = ((u32)(unsigned char)iso) ^ (bias & 0x80u);
+    const u32 tl = (t & 0x7fu) * 0x01010101u;
+    const bool thigh = (t & 0x80u) != 0;                // wave-uniform
+    const u32 w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+    u32 acc[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u32 x = w[j] ^ bias;
+      const u32 d = bop3_32<0xEA>(x, 0x7f7f7f7fu, 0x80808080u) - tl;              // (x & 0x7f..) | 0x80..
+      const u32 ge = thigh ? bop3_32<0x80>(x, d, 0x80808080u) : bop3_32<0xA8>(x, d, 0x80808080u);   // (x &| d) & 0x80..
+      acc[j >> 1] = __builtin_amdgcn_udot4(ge, (j & 1) ? 0x80402010u : 0x08040201u, acc[j >> 1], false);
+    }
+    return (acc[0] >> 7) | (acc[1] << 1);
+  } else if constexpr (sizeof(T) == 1) {
     // 1-byte pixels, SWAR on the packed dwords (byte-wise extraction would blow the 16 bytes of every
     // load up into 16 registers: 146 VGPRs and 3 waves per SIMD instead of 8).  Per byte, unsigned
     // x >= t: with xl, tl the low 7 bits, bit 7 of ((xl | 0x80) - tl) says xl >= tl (no borrow crosses
@@ -170,7 +196,9 @@ __device__ __forceinline__ u64 group_or(u64 part) {
 // write-through (sc1) stores in one burst; the grid is two workgroups per CU.
 constexpr int SPAN_WORDS = 4096;
 
-template <class T>
+// VAR (development, cuberille::Tuning::classify_variant): 0 what ships; 2: the 1-byte pixels' older gather (32-bit
+// multiply); 3: the next trip's loads issued before this trip's arithmetic
+template <class T, int VAR = 0>
 __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
                                                        double isoD, long long isoI, u32 *__restrict__ sliceOcc,
                                                        int lgWordsPerSlice) {
@@ -187,21 +215,40 @@ __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox
   const bool last = sub == LPW - 1;
   for (u64 sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
     const u64 c0 = sp * (u64)(4 * TRIPS * U);            // first 1 KiB chunk of the span
-#pragma unroll 1
-    for (int i = 0; i < TRIPS; i++) {
-      const int tl = i * 4 + wib;                        // the waves take the span's trips in turn
-      Vec16<T> r[U];
+    auto load = [&](Vec16<T> (&r)[U], int tl) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint4 *src = reinterpret_cast<const uint4 *>(vox + ((c0 + (u64)tl * U + u) * 64 + lane) * VPL);
         r[u].raw.x = __builtin_nontemporal_load(&src->x); r[u].raw.y = __builtin_nontemporal_load(&src->y);
         r[u].raw.z = __builtin_nontemporal_load(&src->z); r[u].raw.w = __builtin_nontemporal_load(&src->w);
       }
+    };
+    auto pack = [&](const Vec16<T> (&r)[U], int tl) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const u32 m = inside_bits<T>(r[u], iso);
+        const u32 m = inside_bits<T, VAR == 2>(r[u], iso);
         const u64 word = group_or<LPW>((u64)m << (sub * VPL));
         if (last) stage[(tl * U + u) * VPL + lane / LPW] = word;
+      }
+    };
+    if constexpr (VAR == 3) {
+      Vec16<T> r[U], nx[U];
+      load(r, wib);
+#pragma unroll 1
+      for (int i = 0; i < TRIPS; i++) {
+        const int tl = i * 4 + wib;                      // the waves take the span's trips in turn
+        if (i + 1 < TRIPS) load(nx, tl + 4);
+        pack(r, tl);
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u].raw = nx[u].raw;
+      }
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < TRIPS; i++) {
+        const int tl = i * 4 + wib;                      // the waves take the span's trips in turn
+        Vec16<T> r[U];
+        load(r, tl);
+        pack(r, tl);
       }
     }
     __syncthreads();
@@ -1941,11 +1988,16 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       // large ranges: whole spans through the staged write-through kernel (below ~256 MiB the caches absorb the
       // word stores and more, smaller workgroups fill the chip better)
       u64 spanWords = 0;
-      if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
+      if (tn.classify_variant != 1 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
         const u64 nspans = nwordsAll / SPAN_WORDS;
         const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU
         const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
-        hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
+        if (tn.classify_variant == 2)
+          hipLaunchKernelGGL((k_classify_span<T, 2>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
+        else if (tn.classify_variant == 3)
+          hipLaunchKernelGGL((k_classify_span<T, 3>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
+        else
+          hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
         spanWords = nspans * SPAN_WORDS;
       }
       const u64 restWords = nwordsAll - spanWords;
