@@ -693,14 +693,16 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
                                                u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
                                                Totals *__restrict__ tot) {
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
-  __shared__ unsigned short queue[COUNT_WB], vlist[COUNT_WB];
+  __shared__ unsigned short queue[COUNT_WB];
   __shared__ u64 segTot[COUNT_WB / 64];
-  __shared__ int nQueued, nVertexWords;
+  __shared__ u64 segVW[COUNT_WB / 64];          // per segment: which of its 64 words create vertices
+  __shared__ u32 segVWPre[COUNT_WB / 64];       // ... and how many such words the block's earlier segments hold
+  __shared__ int nQueued;
   __shared__ u32 vbase, g0InSeg;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
-  if (tid == 0) { nQueued = 0; nVertexWords = 0; g0InSeg = 0; }
+  if (tid == 0) { nQueued = 0; g0InSeg = 0; }
   __syncthreads();
   for (int i = tid; i < COUNT_WB; i += 256) {
     const size_t gi = w0 + i;
@@ -738,18 +740,9 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
 #pragma unroll
     for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
     cnt[i] |= (u32)nV;
-    // words that create vertices go to the global vertex-word queue (the point pass runs one lane per
-    // such word)
-    if (nV && vqueue) vlist[atomicAdd(&nVertexWords, 1)] = (unsigned short)i;
   }
   if (errBits) atomicOr(&tot->err, errBits);
   __syncthreads();
-  if (vqueue) {
-    const int nvw = nVertexWords;
-    if (tid == 0 && nvw) vbase = atomicAdd(&tot->nVertexWords, (u32)nvw);   // one global atomic per block
-    __syncthreads();
-    for (int j = tid; j < nvw; j += 256) vqueue[vbase + j] = (u32)(w0 + vlist[j]);
-  }
   for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
     const size_t gi = w0 + sg * 64 + lane;
     const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
@@ -757,8 +750,22 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
     if (gi < nwords) prefix[gi] = incl - packed;
     if (gi == g0) g0InSeg = incl - packed;
     if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
+    // words that create vertices go to the global vertex-word queue IN ORDER (the point pass runs one lane per such
+    // word; a wave of it then owns one contiguous run of vertex ids): their places follow from these ballots
+    const u64 vm = __ballot((packed & 0xffffu) != 0u);
+    if (lane == 0) segVW[sg] = vm;
   }
   __syncthreads();
+  if (vqueue) {
+    if (wv == 1) {
+      // (wave 1, beside wave 0's segment scan below: 32 segment counts -> exclusive prefix, one global atomic per block)
+      const u32 n = lane < COUNT_WB / 64 ? (u32)__popcll(segVW[lane]) : 0u;
+      const u32 incl = wave_inclusive_sum(n);
+      if (lane < COUNT_WB / 64) segVWPre[lane] = incl - n;
+      const u32 total = __shfl(incl, 63, 64);
+      if (lane == 0 && total) vbase = atomicAdd(&tot->nVertexWords, total);
+    }
+  }
   if (MODE & 2) return;
   if (wv == 0) {
     // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
@@ -772,6 +779,14 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
       tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
     }
     if (lane == COUNT_WB / 64 - 1) blockTot[blockIdx.x] = incl;
+  }
+  if (vqueue) {
+    __syncthreads();
+    for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
+      const u64 vm = segVW[sg];
+      if ((vm >> lane) & 1ull)
+        vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
+    }
   }
 }
 
@@ -854,6 +869,7 @@ struct EmitArgs {
   const Totals *rows;  // cuberille_step_end: the gathered totals of all ranks (device memory), or null
   int nRanks, rank;    //   -> this rank's point id offset = owned points of the ranks below; any flag on any rank: no cells
   int dyn;             // the launch was sized blindly (cuberille_step_begin): sizes from `tot`, and only when tot->go
+  int noTwoPhase;      // development switch (Tuning::cells_variant 1): the one-lane-per-quad search of round 2
 };
 
 // absolute exclusive prefix (SHIFT 0: vertices, 16: quads) at the start of the segment that holds word gi
@@ -1256,6 +1272,73 @@ __device__ __forceinline__ bool locate_quad(const EmitArgs &a, const Grid &g, si
   return true;
 }
 
+// The same in two phases per wave (the shape of k_emit_points_dense).  The wave's 64 outputs come from a short run of
+// words that starts at head[first / 64].  Phase 1, one lane per WORD of a 64-word window: its absolute prefix says
+// which outputs it produces; it forms its six face masks once and walks its quads in order (voxel, then face, as
+// txx:197-202 emits them), writing a 2-byte descriptor (source lane, voxel, face) for every output that falls into the
+// wave's range.  Phase 2, one lane per QUAD: descriptor -> voxel and face.  The six face masks are formed once per word
+// instead of once per quad, and the search for the r-th face bit (six popcounts at each of six levels, on every lane)
+// is gone.  Windows slide while outputs stay uncovered (sparse surfaces); what four windows do not cover is searched
+// for per lane as before.  Returns whether this lane's quad was found.  All 64 lanes call this together.
+__device__ __forceinline__ bool locate_quads_wave(const EmitArgs &a, const Grid &g, size_t nwords, unsigned short *qdesc, u64 q,
+                                                  bool valid, u64 Q0, int &x, int &y, int &z, int &f) {
+  const int lane = threadIdx.x & 63;
+  const u64 first = __shfl(q + Q0, 0, 64);       // lane 0 is always valid; a multiple of 64
+  size_t w0 = a.headQ[first >> 6];
+  qdesc[lane] = 0xffffu;
+  bool found = false;
+  for (int slide = 0; slide < 4; slide++) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t w = w0 + lane;
+    if (w < nwords) {
+      const u64 A = seg_base<16>(a, w) + ((a.prefix[w] >> 16) & 0xffffu);
+      const long long rel = (long long)(A - first);          // first output of word w relative to the wave's first
+      if (rel < 64) {                                        // (the head word starts at most one word's worth below 0)
+        int wk, wy, wz;
+        word_coords(g, w, wk, wy, wz);
+        if (a.bits[((size_t)wz * g.ny + wy) * g.W + wk] != 0) {
+          u64 F[6];
+          faces_word(a.bits, g, wy, wz, wk, F);
+          u64 any = F[0] | F[1] | F[2] | F[3] | F[4] | F[5];
+          int o = (int)rel;
+          while (any && o < 64) {
+            const int bx = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            unsigned fm = 0;
+#pragma unroll
+            for (int ff = 0; ff < 6; ff++) fm |= (unsigned)((F[ff] >> bx) & 1ull) << ff;
+            while (fm && o < 64) {
+              const int ff = __ffs((int)fm) - 1;
+              fm &= fm - 1;
+              if (o >= 0) qdesc[o] = (unsigned short)((lane << 9) | (bx << 3) | ff);
+              o++;
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned d = qdesc[lane];
+    if (valid && !found && d != 0xffffu) {
+      int k;
+      word_coords(g, w0 + (d >> 9), k, y, z);
+      x = k * 64 + (int)((d >> 3) & 63u);
+      f = (int)(d & 7u);
+      found = true;
+      qdesc[lane] = 0xfffeu;                                 // taken: a later window leaves it alone
+    }
+    if (!__ballot(valid && !found)) break;
+    // (a descriptor written in a later window for an output found already cannot happen: outputs are monotone in the
+    //  words, and a window only writes outputs its words produce)
+    w0 += 64;
+  }
+  return found;
+}
+
 // a wave's NV ids per quad are 32 or 48 contiguous bytes per lane, 2 or 3 KiB per wave: staged through LDS so that the
 // wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
 template <int NV>
@@ -1284,6 +1367,7 @@ template <bool TRI, bool MAP>
 __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nwords, u64 nQ) {
   constexpr int NV = TRI ? 6 : 4;                // ids per quad
   __shared__ u64 stage[4][64 * NV];
+  __shared__ unsigned short qdesc[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 waveFirst = q - lane;
@@ -1305,7 +1389,19 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
   }
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
   int x, y, z, f;
-  if (locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f)) {
+  bool have = false;
+  const bool valid = q < nQ;
+  if (a.headQ && (Q0 & 63) == 0 && !a.noTwoPhase) {
+    have = locate_quads_wave(a, g, nwords, qdesc[wv], q, valid, Q0, x, y, z, f);
+    if (valid && !have) {                          // beyond four windows: the per-lane search through the prefix levels
+      EmitArgs b = a;
+      b.headQ = nullptr;
+      have = locate_quad(b, g, nwords, q, true, Q0, x, y, z, f);
+    }
+  } else {
+    have = locate_quad(a, g, nwords, q, valid, Q0, x, y, z, f);
+  }
+  if (have) {
     u64 lid[4], o[NV];
     quad_corners<MAP>(a, g, x, y, z, f, lid);
     finish_cell<TRI>(a, V0, totV, lid, o);
@@ -1562,8 +1658,10 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // the escape list untouched and is walked again from its start once the deeper halo is there (MODE 2: the vertices
 // are taken from that list; `g` then describes the deeper buffer).  dyn (cuberille_step_begin): the launch was sized
 // blindly, the real counts are read from `tot`.
-template <class T, int MODE>
-__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+// F64C (development, Tuning::proj_f64cache; round-3 review item 5): the cached site gradients held as doubles -- the 24
+// conversions happen once per gather instead of once per pass -- at the price of the fourth wave per SIMD.
+template <class T, int MODE, bool F64C = false>
+__global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
                                                  int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
                                                  u32 *__restrict__ escList, u32 escCap, int dyn) {
@@ -1606,6 +1704,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   unsigned numberOfSteps = 0;
   int kc[3] = {-2, -2, -2};                        // cell held in registers, named by its clamped floor indices
   float G[8][3];
+  double Gd[F64C ? 8 : 1][3];
   typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
   bool unitP2I = true;
@@ -1667,6 +1766,15 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         }
         cellFinite = (tf == 0.0f) && (td == 0.0);
         if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);   // rare: the reference's formula to the letter
+        if (F64C) {
+#pragma unroll
+          for (int counter = 0; counter < 8; counter++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              Gd[counter][k] = (double)G[counter][k];
+              asm volatile("" : "+v"(Gd[counter][k]));       // (or the compiler keeps the floats and converts at every use)
+            }
+        }
       }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
       // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite
@@ -1696,7 +1804,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 #pragma unroll
         for (int counter = 0; counter < 8; counter++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (F64C ? Gd[F64C ? counter : 0][k] : (double)G[counter][k]);
           value += o[counter] * (double)Vd[counter];
         }
       } else {
@@ -1705,7 +1813,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         for (int counter = 0; counter < 8; counter++) {
           if (o[counter] != 0.0 && total != 1.0) {   // "if (overlap)" + "break once total == 1"
 #pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (F64C ? Gd[F64C ? counter : 0][k] : (double)G[counter][k]);
             value += o[counter] * (double)Vd[counter];
             total += o[counter];
           }
@@ -2069,7 +2177,7 @@ static EmitArgs emit_args(const Workspace &w, const Grid &g, int q1, u64 pointOf
   a.cmap = w.cmap;
   a.headV = w.headV; a.headQ = w.headQ;
   a.extIds = nullptr;
-  a.rows = nullptr; a.nRanks = 0; a.rank = 0; a.dyn = 0;
+  a.rows = nullptr; a.nRanks = 0; a.rank = 0; a.dyn = 0; a.noTwoPhase = 0;
   return a;
 }
 
@@ -2131,12 +2239,14 @@ hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64
 }
 
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
-                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s) {
+                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, const Tuning &tn,
+                             hipStream_t s) {
   if (!nQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   EmitArgs a = emit_args(w, g, q1, pointOffset);
   a.extIds = extIds;
   a.rows = rows; a.nRanks = nRanks; a.rank = rank; a.dyn = dyn;
+  a.noTwoPhase = tn.cells_variant == 1;
   const dim3 grid(grid_for(nQ, 256, 0)), block(256);
   if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nwords, nQ);
   else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nwords, nQ);
@@ -2178,6 +2288,10 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
                        w.escCap, dyn)
     if (mode == 1) CUBERILLE_LAUNCH_PROJECT(1);
     else if (mode == 2) CUBERILLE_LAUNCH_PROJECT(2);
+    else if (tn.proj_f64cache && std::is_same<T, float>::value)
+      hipLaunchKernelGGL((k_project<float, 0, true>), dim3(blocks), dim3(256), 0, s, (const float *)w.vox, g, geo, p, dirIdentity,
+                         w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,
+                         w.escCap, dyn);
     else CUBERILLE_LAUNCH_PROJECT(0);
 #undef CUBERILLE_LAUNCH_PROJECT
     return hipGetLastError();

@@ -6,6 +6,7 @@
 #   gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_hbm.csv, <tag>_bench_under_rocprof.json
 # which are copied into profiles/ by hand once looked at.
 set -e
+set +e   # (a counter pass that dies -- rocprofv3 has done so on large volumes -- must not cost the others)
 TAG=${1:-r1}; shift || true
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
@@ -18,3 +19,5 @@ echo "FETCH_SIZE pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 "$@" > /dev/null 2> "$OUT/write.err"
 echo "WRITE_SIZE pass done"
 python3 "$R/profiles/summarize.py" "$OUT" "$R/gpurun_out/$TAG"
+# the raw traces are tens of MiB per pass (gpurun brings back 64 MiB at most): the summaries are what is kept
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write"
