@@ -400,7 +400,7 @@ int count_launch(cuberille_ctx *c, const Gate &gate) {
   hipStream_t s = c->stream;
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   HIP_TRY(c, launch_occupancy(c->w, c->g, s));
-  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, s));
+  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, c->tune.count_variant, s));
   HIP_TRY(c, hipEventRecord(c->ev[2], s));
   return CUBERILLE_OK;
 }
@@ -1120,7 +1120,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(cells_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(proj_f64cache) OPT(stage_timing)
+  OPT(points_variant) OPT(cells_variant) OPT(count_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(proj_f64cache) OPT(stage_timing)
 #undef OPT
   return false;
 }

@@ -94,7 +94,8 @@ struct Tuning {
   int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
-  int cells_variant = 0;      // 0 two phases per wave (a lane per word of the window, then a lane per quad), 1 a lane per quad
+  int count_variant = 1;      // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory
+  int cells_variant = 1;      // 1 a lane per quad (ships), 0 two phases per wave (a lane per word of the window, then a lane per quad: measured slower)
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
   int proj_f64cache = 0;      // 1 (float pixels): site gradients cached as doubles, three waves per SIMD
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
@@ -121,7 +122,7 @@ struct Gate {
 hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, const Params &p, int z0, int z1, const Tuning &t,
                            hipStream_t s);
 hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s);
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, hipStream_t s);
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s);
 hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, int dyn, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
                               const Tuning &t, int dyn, hipStream_t s);

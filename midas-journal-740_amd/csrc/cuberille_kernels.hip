@@ -456,6 +456,20 @@ __device__ __forceinline__ WordPos word_pos(const u64 *__restrict__ bits, const 
   return w;
 }
 
+// The same word inside a staged copy of the bit rows (the count kernel's LDS tile): `q` points at the word's copy, rows
+// are W words apart as in memory, the slices z-1 / z+1 sit `plane` words before / after.
+__device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long plane, const Grid &g, int y, int z, int k) {
+  WordPos w;
+  w.q = q;
+  w.k = k; w.y = y; w.z = z;
+  w.km = k > 0 ? -1 : 0;
+  w.kp = k < g.W - 1 ? 1 : 0;
+  const long long rs = g.W;
+  w.yo[0] = y > 0 ? -rs : 0;          w.yo[1] = 0;  w.yo[2] = y < g.ny - 1 ? rs : 0;
+  w.zo[0] = z > 0 ? -plane : 0;       w.zo[1] = 0;  w.zo[2] = z < g.nzb - 1 ? plane : 0;
+  return w;
+}
+
 // the row at word offset `off` from the word: three unconditional loads (all loads of a neighbourhood are
 // independent and issue back to back, one memory latency in total), the selects are ALU
 __device__ __forceinline__ Rows3 load_row(const WordPos &w, const Grid &g, long long off) {
@@ -623,12 +637,14 @@ __device__ __forceinline__ void alias_exists(const WordPos &w, const Grid &g, in
 
 // The eight "voxel x creates its corner i" masks of one word (and, FACES, its six face masks).
 // `unknown`: ERRF_* bits of alias_of for the count kernel to raise; the other callers ignore them.
+// wp: where the word's rows are read from (the bit volume, or a staged copy of it); bits: the bit volume itself, for
+// the aliased source slice of quirk Q1 (any slice of the buffer: never staged)
 template <bool FACES>
-__device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, const u32 *__restrict__ occ, const Grid &g, int q1,
-                                              int y, int z, int k, WordInfo &w, u32 &unknown) {
+__device__ __forceinline__ void classify_word_at(const WordPos &wp, const u64 *__restrict__ bits, const u32 *__restrict__ occ,
+                                                 const Grid &g, int q1, WordInfo &w, u32 &unknown) {
+  const int y = wp.y, z = wp.z;
   const bool yzBorder = y == 0 || y == g.ny - 1 || z == 0 || z == g.nzb - 1;
   const bool anyBorder = __ballot(yzBorder) != 0ull;      // uniform over the lanes that are here
-  const WordPos wp = word_pos(bits, g, y, z, k);
   Neigh n;
   u64 anyFace;
   if (anyBorder) {
@@ -654,18 +670,26 @@ __device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, cons
   const int zp = alias_of(occ, g, q1, z, unknown);
   if (zp >= 0) {
     u64 AE[4];
-    alias_exists(wp, g, zp, AE);
+    alias_exists(word_pos(bits, g, y, z, wp.k), g, zp, AE);
 #pragma unroll
     for (int i = 0; i < 4; i++) w.C[i] &= ~AE[i];
   }
 }
 
+template <bool FACES>
+__device__ __forceinline__ void classify_word(const u64 *__restrict__ bits, const u32 *__restrict__ occ, const Grid &g, int q1,
+                                              int y, int z, int k, WordInfo &w, u32 &unknown) {
+  classify_word_at<FACES>(word_pos(bits, g, y, z, k), bits, occ, g, q1, w, unknown);
+}
+
 // the six face masks of a word only (7 bit-rows instead of 27)
-__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
-  const WordPos w = word_pos(bits, g, y, z, k);
+__device__ __forceinline__ void faces_at(const WordPos &w, const Grid &g, u64 F[6]) {
   const Rows3 c = load_row(w, g, 0);
   const u64 ym = w.q[w.yo[0]], yp = w.q[w.yo[2]], zm = w.q[w.zo[0]], zp = w.q[w.zo[2]];
   F[0] = c.c & ~c.m; F[1] = c.c & ~ym; F[2] = c.c & ~c.p; F[3] = c.c & ~yp; F[4] = c.c & ~zm; F[5] = c.c & ~zp;
+}
+__device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k, u64 F[6]) {
+  faces_at(word_pos(bits, g, y, z, k), g, F);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,9 +710,20 @@ __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independe
   return (u64)wave_inclusive_sum((u32)v) | ((u64)wave_inclusive_sum((u32)(v >> 32)) << 32);
 }
 
-// (5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill too much)
-template <int MODE>   // 0 in the library; 2: no block scan, 4: no corner logic (profiles/microbench/count_sweep.hip)
-__global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
+// TILED: every bit row the block reads -- the rows of its own 2048 words, one row before and after, the same of the
+// slices below and above -- is first copied into LDS as three contiguous, coalesced ranges (rows are consecutive in the
+// flat order; ~54-58 KB), and the face tests and the corner logic read the copy: the 27 rows of a surface word are
+// then 27 LDS reads (2 cycles per wave-instruction) instead of 27 trips through the vector cache (8 cycles each, and
+// a queue of surface words is unordered, so nothing coalesces), which is what bounds this kernel once most words
+// carry faces (2048^3 uint8 noise: 2.2 ms untiled, the figure in DESIGN.md tiled).  Two workgroups of 512 fit a CU.
+// Rows wider than TILE_WMAX words (nx > 6144) take the untiled form.
+constexpr int TILE_WMAX = 96;
+constexpr int TILE_PLANE = COUNT_WB + 4 * TILE_WMAX;      // words per staged slice: the block's rows (two of them partly) + 2
+
+// (untiled, 5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill
+//  too much)
+template <int MODE, bool TILED, int NT>   // MODE 0 in the library; 2: no block scan, 4: no corner logic (microbench)
+__global__ __launch_bounds__(NT, (TILED ? 4 : 5)) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
                                                size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
                                                u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
                                                Totals *__restrict__ tot) {
@@ -699,22 +734,52 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
   __shared__ u32 segVWPre[COUNT_WB / 64];       // ... and how many such words the block's earlier segments hold
   __shared__ int nQueued;
   __shared__ u32 vbase, g0InSeg;
+  __shared__ u64 tile[TILED ? 3 * TILE_PLANE : 1];
+  constexpr int NWAVES = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
   if (tid == 0) { nQueued = 0; g0InSeg = 0; }
+  long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
+  if (TILED) {
+    int k0, y0, z0, k1, y1, z1;
+    word_coords(g, w0, k0, y0, z0);
+    const size_t wl = w0 + COUNT_WB - 1 < nwords ? w0 + COUNT_WB - 1 : nwords - 1;
+    word_coords(g, wl, k1, y1, z1);
+    rowFirst = (long long)z0 * g.ny + y0;
+    const long long rowLast = (long long)z1 * g.ny + y1;
+    const int len = (int)(rowLast - rowFirst + 3) * g.W;    // the block's rows, one before, one after
+    const long long nbuf = (long long)g.nzb * g.ny * g.W;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
+      for (int j = tid; j < len; j += NT) {
+        const long long gidx = gstart + j;
+        tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+      }
+    }
+  }
   __syncthreads();
-  for (int i = tid; i < COUNT_WB; i += 256) {
+  // where word (k, y, z) of this block is read from
+  auto at = [&](int k, int y, int z) -> WordPos {
+    if (TILED) {
+      const long long t = (long long)z * g.ny + y - rowFirst + 1;
+      return word_pos_tile(&tile[TILE_PLANE + t * g.W + k], TILE_PLANE, g, y, z, k);
+    }
+    return word_pos(bits, g, y, z, k);
+  };
+  for (int i = tid; i < COUNT_WB; i += NT) {
     const size_t gi = w0 + i;
     u32 packed = 0;
     if (gi < nwords) {
       int k, y, z;
       word_coords(g, gi, k, y, z);
+      const WordPos wp = at(k, y, z);
       // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
       // whole runs of such words, so whole waves take the short way)
-      if (bits[((size_t)z * g.ny + y) * g.W + k] != 0) {
+      if (wp.q[0] != 0) {
         u64 F[6];
-        faces_word(bits, g, y, z, k, F);
+        faces_at(wp, g, F);
         int nQ = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
@@ -727,14 +792,14 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
   __syncthreads();
   const int nq = (MODE & 4) ? 0 : nQueued;
   u32 errBits = 0;
-  for (int j = tid; j < nq; j += 256) {
+  for (int j = tid; j < nq; j += NT) {
     const int i = queue[j];
     const size_t gi = w0 + i;
     int k, y, z;
     word_coords(g, gi, k, y, z);
     WordInfo w;
     u32 unknown;
-    classify_word<false>(bits, occ, g, q1, y, z, k, w, unknown);
+    classify_word_at<false>(at(k, y, z), bits, occ, g, q1, w, unknown);
     errBits |= unknown;
     int nV = 0;
 #pragma unroll
@@ -743,7 +808,7 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
   }
   if (errBits) atomicOr(&tot->err, errBits);
   __syncthreads();
-  for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
+  for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
     const size_t gi = w0 + sg * 64 + lane;
     const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
     const u32 incl = wave_inclusive_sum(packed);
@@ -782,7 +847,7 @@ __global__ __launch_bounds__(256, 5) void k_count(const u64 *__restrict__ bits, 
   }
   if (vqueue) {
     __syncthreads();
-    for (int sg = wv; sg < COUNT_WB / 64; sg += 4) {
+    for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
       const u64 vm = segVW[sg];
       if ((vm >> lane) & 1ull)
         vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
@@ -2156,10 +2221,15 @@ hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, hipStream_t s) {
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
-  hipLaunchKernelGGL(k_count<0>, dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot,
-                     nwords < 0xffffffffULL ? w.vqueue : nullptr, w.totals);
+  u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
+  if (tiled && g.W <= TILE_WMAX)
+    hipLaunchKernelGGL((k_count<0, true, 512>), dim3(blocks), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                       w.blockTot, vq, w.totals);
+  else
+    hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                       w.blockTot, vq, w.totals);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
   hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate);
   return hipGetLastError();
