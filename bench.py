@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--full-halo", action="store_true", help="N>1: exchange the whole projection-reach halo every step")
     ap.add_argument("--host-offsets", action="store_true",
                     help="N>1: the count all-gather through the host (two more host waits per step) instead of device-resident rows")
+    ap.add_argument("--opt", action="append", default=[],
+                    help="development: name=value for cuberille_debug_set_option (kernel variants; results never depend on them)")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="N=1: skip the extra measurement of one 1/8 slab (what a rank of an 8-GPU run does per step)")
     args = ap.parse_args()
@@ -222,6 +224,8 @@ def main():
     strong = world == 1 or args.scaling == "strong"
     gnz = n if strong else n * world
     ex = pkg.Extractor(local_rank)
+    for kv in args.opt:
+        ex.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     # (weak mode stacks copies of the block along z; for Marschner-Lobb every copy ends in a run of empty slices, across
     #  which the reference re-uses vertex ids -- quirk Q1, DESIGN.md -- at every slab boundary: the driver hands the
     #  source slices between the ranks, two more small exchanges per step)

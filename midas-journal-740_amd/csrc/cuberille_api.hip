@@ -85,6 +85,8 @@ struct cuberille_ctx {
   bool counted = false, haveMesh = false, slabMesh = false;
   bool pointsEmitted = false;            // the offset-free part of the emit has been launched for the current count
   bool stagesTimed = false;              // the per-stage events of the running count/emit pair are being recorded
+  bool lightTiming = false;              // a few million voxels at most: ONE event pair around the extraction (every event
+                                         // between two kernels costs the stream about as much as such a volume's kernels)
   Grid g{};
   Geo geo{};
   Params prm{};
@@ -389,6 +391,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(w.totals, 0, sizeof(Totals) + (size_t)g.nzb * sizeof(u32), s));
   c->stagesTimed = c->tune.stage_timing != 0;
+  c->lightTiming = !c->stagesTimed && (u64)g.nx * (u64)g.ny * (u64)g.nzb <= (4ull << 20);
   HIP_TRY(c, hipEventRecord(c->ev[0], s));
   c->g = g; c->geo = geo; c->prm = p; c->pixel_type = img->pixel_type; c->w = w;
   c->nwords = nwords; c->nseg = nseg;
@@ -399,9 +402,9 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
 int count_launch(cuberille_ctx *c, const Gate &gate) {
   hipStream_t s = c->stream;
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  HIP_TRY(c, launch_occupancy(c->w, c->g, s));
+  HIP_TRY(c, launch_occupancy(c->pixel_type, c->w, c->g, c->tune, s));
   HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, c->tune.count_variant, s));
-  HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   return CUBERILLE_OK;
 }
 
@@ -633,7 +636,7 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   if (dyn && (!w.cmap || !w.headQ || !w.vqueue || c->tune.points_variant != 3))
     return fail(c, CUBERILLE_ERR_STATE, "internal: blind launch without the scratch tables");
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipEventRecord(c->ev[4], s));
+  if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   HIP_TRY(c, launch_heads(w, c->g, nV, totQ, dyn ? 1 : 0, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, nVW, c->tune, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
@@ -661,12 +664,19 @@ int finish_result(cuberille_ctx *c, cuberille_result *res) {
     HIP_TRY(c, hipEventElapsedTime(&r.ms_emit_cells, c->pointsStartedEarly ? c->ev[3] : c->ev[6], c->ev[7]));
   }
   float b = 0.f, b2 = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
-  if (c->pointsStartedEarly) {
-    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[6]));
-    HIP_TRY(c, hipEventElapsedTime(&b2, c->ev[3], c->ev[7]));
+  if (c->lightTiming) {
+    // one event pair: the whole extraction as the stream saw it (a host turn between count and emit included, where
+    // the caller took one); no pass figure
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[0], c->ev[7]));
+    r.ms_pass = 0.f;
   } else {
-    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
+    if (c->pointsStartedEarly) {
+      HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[6]));
+      HIP_TRY(c, hipEventElapsedTime(&b2, c->ev[3], c->ev[7]));
+    } else {
+      HIP_TRY(c, hipEventElapsedTime(&b, c->ev[4], c->ev[7]));
+    }
   }
   r.ms_total = r.ms_pass + b + b2;           // device time: the host's turn between count and emit is in none of the intervals
   r.proj_iterations = c->tot.iters;
@@ -708,7 +718,7 @@ int cuberille_emit_points(cuberille_ctx *c) {
   rc = emit_points_phase(c);
   if (rc) return rc;
   // the caller turns to the other ranks now: this phase gets its own end mark, cuberille_emit starts a second interval
-  if (!c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+  if (!c->stagesTimed && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
   c->pointsStartedEarly = true;
   return CUBERILLE_OK;
 }
@@ -786,7 +796,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result 
   hipStream_t s = c->stream;
   // the vertex phase was started ahead of this call (cuberille_emit_points): the device may have idled since, waiting
   // for the host's all-gather -- the cell phase is timed as an interval of its own
-  if (c->pointsStartedEarly) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  if (c->pointsStartedEarly && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr,
@@ -846,7 +856,7 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
     }
   }
   if (c->pointsEmitted) {
-    if (!c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+    if (!c->stagesTimed && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
     c->pointsStartedEarly = true;
   }
   *dev_row = c->w.totals;
@@ -872,7 +882,7 @@ int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank,
     HIP_TRY(c, hipHostMalloc((void **)&c->hostRows, (size_t)n_ranks * sizeof(Totals), hipHostMallocDefault));
     c->hostRowsCap = (size_t)n_ranks;
   }
-  HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   // the cells, unless a flag stands somewhere (the kernel looks at the rows itself: every rank decides alike).  Sized
   // by the cover values (blind) or by this rank's counts; a rank whose vertex phase did not run launches nothing.
   if (blind || c->pointsEmitted) {

@@ -2140,6 +2140,16 @@ static int occupancy_shift(const Grid &g) {
   return lg;
 }
 
+// Volumes of a few million voxels (every volume the reference ships) are bound by the NUMBER of launches, not by any
+// of them: their ragged rows go through the one-wave-per-word kernel (one launch that also marks the slice occupancy)
+// instead of the flat stream's three launches and the occupancy pass.
+static bool small_volume(const Grid &g) { return (u64)g.nx * (u64)g.ny * (u64)g.nzb <= (4ull << 20); }
+
+// ragged rows: does the sweep go through the flat stream (k_classify_flat + tail + repack; occupancy derived afterwards)?
+static bool ragged_stream_path(const Workspace &w, const Grid &g, size_t elem, const Tuning &tn) {
+  return g.nx % 64 != 0 && w.flatBits && ((uintptr_t)w.vox % elem) == 0 && !tn.no_stream_classify && !small_volume(g);
+}
+
 // classify slices [z0, z1) of the buffer (a z-range is a contiguous range of voxels and of words)
 hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g, const Params &prm, int z0, int z1,
                            const Tuning &tn, hipStream_t s) {
@@ -2184,7 +2194,7 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       if (spanWords + nchunks * VPL < nwordsAll)
         hipLaunchKernelGGL((k_classify_rows<T>), dim3(1), dim3(256), 0, s, vox, w.bits, g.nx, g.W, spanWords + nchunks * VPL, nrows,
                            (u64)g.ny, iso, isoI, w.sliceOcc);
-    } else if (wAll.flatBits && ((uintptr_t)vox % sizeof(T)) == 0 && !tn.no_stream_classify) {
+    } else if (ragged_stream_path(wAll, g, sizeof(T), tn)) {
       // ragged rows: flat stream of aligned 16-byte vectors (the first and last vector may reach up to 15 bytes
       // outside the range -- same 16-byte granule as valid voxels, so the loads cannot fault, and those bits
       // are never used), then cut into rows.  Each z-range uses its own part of the scratch.
@@ -2215,8 +2225,13 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
 }
 
 // per-slice occupancy from the packed bits where the sweep could not set it on the fly
-hipError_t launch_occupancy(const Workspace &w, const Grid &g, hipStream_t s) {
-  if (occupancy_shift(g) < 0 || ((uintptr_t)w.vox % 16) != 0)
+// (the one-wave-per-word kernel marks the occupancy itself: rows that are not whole words off the stream path, and
+//  whole-word rows behind a pointer that is not 16-byte aligned)
+hipError_t launch_occupancy(int pixel_type, const Workspace &w, const Grid &g, const Tuning &tn, hipStream_t s) {
+  size_t elem = 1;
+  (void)by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t { elem = sizeof(*tag); return hipSuccess; });
+  const bool aligned = g.nx % 64 == 0 && ((uintptr_t)w.vox % 16) == 0;
+  if ((aligned && occupancy_shift(g) < 0) || ragged_stream_path(w, g, elem, tn))
     hipLaunchKernelGGL(k_occupancy, dim3(g.nzb), dim3(256), 0, s, w.bits, (size_t)g.ny * g.W, w.sliceOcc);
   return hipGetLastError();
 }
