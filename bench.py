@@ -320,6 +320,8 @@ def main():
         alg_bytes = float(n) * n * (sh.hi - sh.lo) * np.dtype(dtype).itemsize
         classify_gbs = alg_bytes / (stages["ms_classify"] * 1e-3) / 1e9
         pass_ms = live["ms_pass"] / args.steps          # HIP events around the pass, every step of the timed region
+        if pass_ms <= 0.0:                              # (volumes of a few M voxels get one event pair only: take the stage events)
+            pass_ms = stages["ms_classify"] + stages["ms_count"]
         pass_gbs = alg_bytes / (pass_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args, world, alg_bytes)
         out = {

@@ -86,12 +86,19 @@ typedef struct {
                                     the reference ships), _ADVANCED (USE_ADVANCED_PROJECTION, txx:340-397) or _LINESEARCH
                                     (USE_LINESEARCH_PROJECTION, txx:398-437) -- the last two are compiled out upstream
                                     (h:22-23); anything else is CUBERILLE_ERR_ARGUMENT */
-  int32_t reserved;              /* 0 */
+  int32_t gradient_variant;      /* the gradient image the walk follows: CUBERILLE_GRADIENT_CENTRAL -- itk::GradientImageFilter, what
+                                    the reference ships (h:166; txx:478-498) -- or CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN:
+                                    USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491, compiled out upstream):
+                                    itk::GradientRecursiveGaussianImageFilter with sigma = the largest spacing and
+                                    NormalizeAcrossScale on.  The reference holds three lines of that; the filter itself is ITK's
+                                    (Deriche's recursive Gaussian), restated from its published algorithm: PARITY UNPINNED.  It
+                                    needs whole lines, so it is refused on slabs, and at least 4 voxels along every axis */
   int64_t iso_value_int;         /* CUBERILLE_PIX_I64 / _U64 only (iso_value is then ignored): the iso value itself, which a
                                     double cannot hold past 2^53; for _U64 the same 64 bits read as unsigned */
 } cuberille_params;
 
 enum { CUBERILLE_PROJECT_DEFAULT = 0, CUBERILLE_PROJECT_ADVANCED = 1, CUBERILLE_PROJECT_LINESEARCH = 2 };
+enum { CUBERILLE_GRADIENT_CENTRAL = 0, CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN = 1 };
 
 /* Z-slab placement for multi-GPU runs (one process per GPU).
  * NULL or all-zero means "the buffer is the whole volume". */
@@ -139,9 +146,10 @@ typedef struct {
   uint64_t n_cells;         /* cells this call/rank owns (quads, or 2 triangles per quad) */
   int32_t verts_per_cell;   /* 4 or 3 */
   int32_t reserved;
-  /* Device time in milliseconds (HIP events on the context's stream).  ms_pass and ms_total are always measured; the five
-   * per-stage figures only with cuberille_debug_set_option(ctx, "stage_timing", 1) and are 0 otherwise: every event
-   * between two kernels costs the stream about 8 us, 1 % of a 1024^3 extraction for the three it takes. */
+  /* Device time in milliseconds (HIP events on the context's stream).  ms_total is always measured, ms_pass for volumes of
+   * more than 4 Mi voxels (below that ONE event pair brackets the extraction and ms_pass is 0: an event between two kernels
+   * costs the stream about 8 us, as much as such a volume's kernels); the five per-stage figures only with
+   * cuberille_debug_set_option(ctx, "stage_timing", 1) and are 0 otherwise. */
   float ms_classify;        /* threshold + bit-pack sweep over the volume */
   float ms_count;           /* per-word face / created-corner counts and all prefix sums (one kernel) */
   float ms_scan;            /* 0: the scans run inside the count kernel since ABI 4 (field kept for layout) */

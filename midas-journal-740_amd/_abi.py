@@ -39,7 +39,7 @@ class Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
                 ("max_steps", C.c_uint32), ("emulate_empty_slice_aliasing", C.c_int32),
-                ("projection_variant", C.c_int32), ("reserved", C.c_int32), ("iso_value_int", C.c_int64)]
+                ("projection_variant", C.c_int32), ("gradient_variant", C.c_int32), ("iso_value_int", C.c_int64)]
 
 
 class Slab(C.Structure):

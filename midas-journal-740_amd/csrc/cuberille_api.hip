@@ -54,6 +54,7 @@ struct cuberille_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   std::string err;
   DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue, escList;
+  DevBuf gradImg, rgA, rgB, rgScratch;   // gradient_variant 1: the gradient image and what its passes go through
   Totals *hostTotals = nullptr;          // pinned
   uint32_t *hostOcc = nullptr;           // pinned mirror of the per-slice occupancy of the last slab count
   size_t hostOccCap = 0;
@@ -156,6 +157,12 @@ int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox,
   }
   if (prm->projection_variant < CUBERILLE_PROJECT_DEFAULT || prm->projection_variant > CUBERILLE_PROJECT_LINESEARCH)
     return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown projection variant");
+  if (prm->gradient_variant < CUBERILLE_GRADIENT_CENTRAL || prm->gradient_variant > CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN)
+    return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown gradient variant");
+  if (prm->gradient_variant == CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN && prm->project_vertices)
+    for (int i = 0; i < 3; i++)
+      if (img->dims[i] < 4)   // (ITK's recursive filter throws for shorter lines)
+        return fail(c, CUBERILLE_ERR_ARGUMENT, "the recursive-Gaussian gradient needs at least 4 voxels along every axis");
   // the iso value is an InputPixelType in the reference (h:180-181): for the integer pixel types it must convert
   // without leaving the type's range (a fraction is cut off like a C cast does)
   double lo = 0.0, hi = 0.0;
@@ -223,7 +230,8 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (c->own) (void)hipStreamSynchronize(c->own);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
-                    &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->escList};
+                    &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->escList,
+                    &c->gradImg, &c->rgA, &c->rgB, &c->rgScratch};
   for (DevBuf *b : bufs) b->release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   if (c->hostOcc) (void)hipHostFree(c->hostOcc);
@@ -291,6 +299,54 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
   p.project = prm->project_vertices != 0;
   p.q1 = prm->emulate_empty_slice_aliasing != 0;
   p.variant = prm->projection_variant;
+  p.gradVariant = prm->gradient_variant;
+}
+
+// RecursiveGaussianImageFilter::SetUp of ITK 3.x (Deriche's fourth-order recursive Gaussian): the 20 coefficients of one
+// separable pass -- order 0 smoothing, order 1 first derivative with NormalizeAcrossScale (txx:490) -- for `sigma` in
+// physical units on an axis of the given spacing.  Evaluated on the host in double, once per extraction; the kernels
+// (k_rg_pass) only run the recurrences.  Layout = cuberille::DericheCoef.
+void deriche_setup(double sigma, double spacing, int order, double out[20]) {
+  static const double A1[2] = {1.3530, -0.6724}, B1[2] = {1.8151, -3.4327}, W1 = 0.6681, L1 = -1.3932;
+  static const double A2[2] = {-0.3531, 0.6724}, B2[2] = {0.0902, 0.6100}, W2 = 2.0787, L2 = -1.3732;
+  const double sigmad = sigma / spacing;
+  const double cos1 = std::cos(W1 / sigmad), cos2 = std::cos(W2 / sigmad), sin1 = std::sin(W1 / sigmad), sin2 = std::sin(W2 / sigmad);
+  const double exp1 = std::exp(L1 / sigmad), exp2 = std::exp(L2 / sigmad);
+  double D4 = exp1 * exp1 * exp2 * exp2;
+  double D3 = -2 * cos1 * exp1 * exp2 * exp2;
+  D3 += -2 * cos2 * exp2 * exp1 * exp1;
+  double D2 = 4 * cos2 * cos1 * exp1 * exp2;
+  D2 += exp1 * exp1 + exp2 * exp2;
+  const double D1 = -2 * (exp2 * cos2 + exp1 * cos1);
+  const double SD = 1.0 + D1 + D2 + D3 + D4;
+  const double DD = D1 + 2 * D2 + 3 * D3 + 4 * D4;
+  const double a1 = A1[order], b1 = B1[order], a2 = A2[order], b2 = B2[order];
+  double N0 = a1 + a2;
+  double N1 = exp2 * (b2 * sin2 - (a2 + 2 * a1) * cos2);
+  N1 += exp1 * (b1 * sin1 - (a1 + 2 * a2) * cos1);
+  double N2 = (a1 + a2) * cos2 * cos1;
+  N2 -= b1 * cos2 * sin1 + b2 * cos1 * sin2;
+  N2 *= 2 * exp1 * exp2;
+  N2 += a2 * exp1 * exp1 + a1 * exp2 * exp2;
+  double N3 = exp2 * exp1 * exp1 * (b2 * sin2 - a2 * cos2);
+  N3 += exp1 * exp2 * exp2 * (b1 * sin1 - a1 * cos1);
+  const double SN = N0 + N1 + N2 + N3;
+  const double DN = N1 + 2 * N2 + 3 * N3;
+  double M1, M2, M3, M4;
+  if (order == 0) {
+    const double alpha0 = 2 * SN / SD - N0;
+    N0 /= alpha0; N1 /= alpha0; N2 /= alpha0; N3 /= alpha0;
+    M1 = N1 - D1 * N0; M2 = N2 - D2 * N0; M3 = N3 - D3 * N0; M4 = -D4 * N0;
+  } else {
+    double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    alpha1 *= 1.0;                                // (spacing is positive here: no sign flip)
+    N0 *= sigma / alpha1; N1 *= sigma / alpha1; N2 *= sigma / alpha1; N3 *= sigma / alpha1;
+    M1 = -(N1 - D1 * N0); M2 = -(N2 - D2 * N0); M3 = -(N3 - D3 * N0); M4 = D4 * N0;
+  }
+  const double sn = N0 + N1 + N2 + N3, sm = M1 + M2 + M3 + M4, sd = 1.0 + D1 + D2 + D3 + D4;
+  const double v[20] = {N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4,
+                        D1 * sn / sd, D2 * sn / sd, D3 * sn / sd, D4 * sn / sd, D1 * sm / sd, D2 * sm / sd, D3 * sm / sd, D4 * sm / sd};
+  for (int i = 0; i < 20; i++) out[i] = v[i];
 }
 
 // First half of a count: layout, parameters, workspace, zeroed state.  The caller then thresholds the slices
@@ -330,6 +386,8 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
     // slice below that) and 1 above; with the projection on, as far as a walk can reach (both unless the
     // volume ends there)
     // (a THIN_HALO slab promises the topology's slices only; walks that want more are put aside, not clamped)
+    if (p.project && p.gradVariant != CUBERILLE_GRADIENT_CENTRAL)
+      return fail(c, CUBERILLE_ERR_ARGUMENT, "the recursive-Gaussian gradient filters whole lines of the volume: not offered on slabs");
     const bool thin = (slab->flags & CUBERILLE_SLAB_THIN_HALO) != 0;
     if (thin && p.project && p.variant != CUBERILLE_PROJECT_DEFAULT)
       return fail(c, CUBERILLE_ERR_ARGUMENT, "a THIN_HALO slab is only offered with the default projection branch");
@@ -640,6 +698,26 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   HIP_TRY(c, launch_heads(w, c->g, nV, totQ, dyn ? 1 : 0, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, nVW, c->tune, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
+  w.gradImg = nullptr;
+  if (c->prm.project && c->prm.gradVariant == CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN && nV) {
+    // the whole-image gradient pre-pass of txx:478-498 in its recursive-Gaussian form (the shipped central differences
+    // are evaluated on the fly inside the walk and never materialised)
+    const size_t nvox = (size_t)c->g.nx * c->g.ny * c->g.nzb;
+    HIP_TRY(c, c->gradImg.reserve(nvox * 3 * sizeof(double)));
+    HIP_TRY(c, c->rgScratch.reserve(nvox * sizeof(double)));
+    HIP_TRY(c, c->rgA.reserve(nvox * sizeof(float)));
+    HIP_TRY(c, c->rgB.reserve(nvox * sizeof(float)));
+    w.gradImg = (double *)c->gradImg.p; w.rgScratch = (double *)c->rgScratch.p;
+    w.rgA = (float *)c->rgA.p; w.rgB = (float *)c->rgB.p;
+    double sigma = c->geo.spacing[0];                        // txx:489: m_MaxSpacing * 1.0
+    for (int i = 1; i < 3; i++) if (c->geo.spacing[i] > sigma) sigma = c->geo.spacing[i];
+    double coef[3][2][20];
+    for (int ax = 0; ax < 3; ax++) {
+      deriche_setup(sigma, c->geo.spacing[ax], 1, coef[ax][0]);
+      deriche_setup(sigma, c->geo.spacing[ax], 0, coef[ax][1]);
+    }
+    HIP_TRY(c, launch_recursive_gaussian(c->pixel_type, w, c->g, c->geo, coef, s));
+  }
   if (c->prm.project)
     HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
@@ -820,7 +898,7 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
   // blind launches need: the sizes of a previous extraction on this context, the default projection branch and every
   // scratch table (the vertex-word queue is set up by count_prepare; the others are checked below)
   const bool blind = c->haveHistory && c->w.vqueue && !c->tune.no_cmap && !c->tune.no_heads && c->tune.points_variant == 3 &&
-                     (!c->prm.project || c->prm.variant == CUBERILLE_PROJECT_DEFAULT) && c->histV + c->histV / 4 < 0xfffff000ULL;
+                     (!c->prm.project || (c->prm.variant == CUBERILLE_PROJECT_DEFAULT && c->prm.gradVariant == 0)) && c->histV + c->histV / 4 < 0xfffff000ULL;
   if (blind) {
     Gate gate{};
     gate.on = 1;

@@ -83,6 +83,9 @@ struct Workspace {     // device pointers valid for one count/emit pair
   u32 *cmap;           // dense lattice-corner -> vertex index map (null: recompute ids instead)
   u32 *headV, *headQ;  // word that produces output 64*i (null: per-lane binary search instead)
   u32 *vqueue;         // counted-range indices of the words that create vertices, in no particular order (or null)
+  double *gradImg;     // gradient_variant 1: the recursive-Gaussian gradient image, 3 doubles per voxel (else null)
+  float *rgA, *rgB;    //   ... and what its passes go through: two float volumes and a double one
+  double *rgScratch;
   u32 *escList;        // THIN_HALO: indices (in this rank's point buffer) of the vertices whose walk left the buffer
   u32 escCap;
 };
@@ -108,6 +111,7 @@ struct Params {
   u32 max_steps;
   int triangles, project, q1;
   int variant;                // CUBERILLE_PROJECT_*
+  int gradVariant;            // CUBERILLE_GRADIENT_*
 };
 
 // cuberille_step_begin: what the launches behind the count were sized for (k_block_scan sets Totals::go accordingly)
@@ -131,6 +135,8 @@ hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, i
                              hipStream_t s);
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
                               hipStream_t s);
+hipError_t launch_recursive_gaussian(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const double coef[3][2][20],
+                                     hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, int mode, int dyn, hipStream_t s);
 

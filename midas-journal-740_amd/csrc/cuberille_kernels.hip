@@ -30,6 +30,7 @@
 #include "../../include/cuberille_hip.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -1970,14 +1971,42 @@ struct VariantCtx {
   bool dirIdentity, unitP2I;
   int n[3];
   double iso;
+  const double *gimg;   // the recursive-Gaussian variant's gradient image (CovariantVector<double,3> per pixel), or null
 };
 
-// I7 + I8: the interpolated gradient at `vertex`, normalised (txx:356-357, 408-409)
+// I7 + I8: the interpolated gradient at `vertex`, normalised (txx:356-357, 408-409, 451-452), as the double vector the
+// step multiplies.  The shipped gradient type is CovariantVector<float,3>: the interpolated sum is narrowed to float
+// and Normalize() rounds each component to float again.  With USE_GRADIENT_RECURSIVE_GAUSSIAN the gradient image holds
+// doubles (x.gimg): interpolation and Normalize() stay in double.
 template <class T>
-__device__ void variant_normal(const VariantCtx<T> &x, const float vertex[3], float normal[3]) {
+__device__ void variant_normal(const VariantCtx<T> &x, const float vertex[3], double nd[3]) {
   const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
   Cell8 c;
   make_cell(x.geo, x.unitP2I, x.n, p, c);
+  if (x.gimg) {
+    double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+#pragma unroll
+    for (unsigned counter = 0; counter < 8; counter++) {
+      double overlap = 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
+      if (overlap != 0.0 && total != 1.0) {
+        const int sx = (counter & 1) ? c.hi[0] : c.lo[0], sy = (counter & 2) ? c.hi[1] : c.lo[1], sz = (counter & 4) ? c.hi[2] : c.lo[2];
+        const double *gp = x.gimg + 3 * (((size_t)sz * x.n[1] + sy) * x.n[0] + sx);
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] += overlap * gp[k];
+        total += overlap;
+      }
+    }
+    double sq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) sq += acc[k] * acc[k];
+    const double norm = sqrt(sq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) nd[k] = acc[k] / norm;
+    return;
+  }
+  float normal[3];
   float G[8][3];
   typename SiteValue<T>::type Vd[8];
   gather_cell<T, true>(x.s, x.geo, x.dirIdentity, c, G, Vd);
@@ -1998,7 +2027,7 @@ __device__ void variant_normal(const VariantCtx<T> &x, const float vertex[3], fl
   for (int k = 0; k < 3; k++) { normal[k] = (float)acc[k]; const double e = (double)normal[k]; sq += e * e; }
   const double norm = sqrt(sq);
 #pragma unroll
-  for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+  for (int k = 0; k < 3; k++) nd[k] = (double)(float)((double)normal[k] / norm);
 }
 
 // I5: the interpolated pixel value at `q` (txx:368-369, 424)
@@ -2025,7 +2054,7 @@ __device__ double variant_value(const VariantCtx<T> &x, const float q[3]) {
 template <class T>
 __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                          float *__restrict__ points, u64 nPoints, u64 nGhost,
-                                                         Totals *__restrict__ tot) {
+                                                         Totals *__restrict__ tot, const double *__restrict__ gimg) {
   const int lane = threadIdx.x & 63;
   const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned passes = 0;
@@ -2040,9 +2069,26 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
     for (int i = 0; i < 9; i++) x.unitP2I = x.unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
     x.n[0] = g.nx; x.n[1] = g.ny; x.n[2] = (int)g.gnz;
     x.iso = (double)iso_as<T>(prm.iso, prm.isoInt);
+    x.gimg = gimg;
     float vertex[3] = {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
-    float normal[3];
-    if (prm.variant == CUBERILLE_PROJECT_ADVANCED) {
+    double normal[3];
+    if (prm.variant == CUBERILLE_PROJECT_DEFAULT) {
+      // txx:439-474 to the letter (the refilling kernel k_project is this branch with the shipped gradient; here for the
+      // recursive-Gaussian one)
+      double step = prm.step;
+      unsigned numberOfSteps = 0;
+      for (;;) {
+        passes++;
+        variant_normal(x, vertex, normal);                                        // txx:451-452
+        const double value = variant_value(x, vertex);                            // txx:455
+        if (fabs(value - x.iso) < prm.thr) { byThr = true; break; }               // txx:456-460
+        const double sign = (value < x.iso) ? +1.0 : -1.0;                        // txx:463
+#pragma unroll
+        for (int k = 0; k < 3; k++) vertex[k] = (float)((double)vertex[k] + (normal[k] * sign * step));   // txx:464-467
+        step *= prm.relax;                                                        // txx:468
+        if (numberOfSteps++ > prm.max_steps) { bySteps = true; break; }           // txx:469-473
+      }
+    } else if (prm.variant == CUBERILLE_PROJECT_ADVANCED) {
       double step = prm.step;
       unsigned numberOfSteps = 0, swaps = 0;
       int previousi = -1;
@@ -2052,8 +2098,8 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
         float temp[2][3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {                                             // txx:360-364
-          temp[0][k] = (float)((double)vertex[k] + ((double)normal[k] * +1.0 * step));
-          temp[1][k] = (float)((double)vertex[k] + ((double)normal[k] * -1.0 * step));
+          temp[0][k] = (float)((double)vertex[k] + (normal[k] * +1.0 * step));
+          temp[1][k] = (float)((double)vertex[k] + (normal[k] * -1.0 * step));
         }
         step *= prm.relax;                                                        // txx:365
         const double d0 = fabs(variant_value(x, temp[0]) - x.iso);                // txx:368-371
@@ -2080,7 +2126,7 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
           float temp[3];
 #pragma unroll
           for (int k = 0; k < 3; k++)                                             // txx:419-422
-            temp[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * prm.step * d));
+            temp[k] = (float)((double)vertex[k] + (normal[k] * sign * prm.step * d));
           const double metric = fabs(variant_value(x, temp) - x.iso);             // txx:424-425
           if (metric < bestMetric) {                                              // txx:430-434
             bestMetric = metric;
@@ -2101,6 +2147,102 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
   const u64 nThr = __ballot(byThr), nSteps = __ballot(bySteps);
   if (lane == 0 && nThr) atomicAdd(&tot->stopThr, (u64)__popcll(nThr));
   if (lane == 0 && nSteps) atomicAdd(&tot->stopSteps, (u64)__popcll(nSteps));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4c: USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491; compiled out upstream): the gradient image of
+// itk::GradientRecursiveGaussianImageFilter, sigma = max spacing, NormalizeAcrossScale on.  The reference holds three
+// lines of it, the rest is ITK's recursive (Deriche, fourth order) separable filter: per component the first-derivative
+// filter along its axis, then the smoothing filter along the two other axes, float images between the passes, the
+// result divided by the spacing.  A line is a recurrence: one lane per line, the causal half forwards (kept in a double
+// scratch volume), the anti-causal half backwards, every sum in the order ITK writes it.  Off the default path and
+// written for exactness, not speed (lines along x are walked with a stride of a row per lane).  Parity unpinned.
+// ---------------------------------------------------------------------------------------------
+struct DericheCoef {
+  double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
+};
+
+template <class TIn>
+__global__ __launch_bounds__(256) void k_rg_pass(const TIn *__restrict__ in, float *__restrict__ out, double *__restrict__ causal,
+                                                 DericheCoef c, long long n0, long long n1, long long n2, int axis) {
+  // lines along `axis`; the lanes of a wave take lines that are neighbours along the lowest other axis
+  const long long n[3] = {n0, n1, n2};
+  const long long stride[3] = {1, n0, n0 * n1};
+  const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+  const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= n[a1] * n[a2]) return;
+  const long long base = (L % n[a1]) * stride[a1] + (L / n[a1]) * stride[a2];
+  const long long st = stride[axis], ln = n[axis];
+  auto D = [&](long long i) -> double { return (double)in[base + i * st]; };
+  const double outV1 = D(0);
+  const double d1 = D(1), d2 = D(2), d3 = D(3);
+  double s0 = outV1 * c.N0 + outV1 * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  double s1 = d1 * c.N0 + outV1 * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  double s2 = d2 * c.N0 + d1 * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  double s3 = d3 * c.N0 + d2 * c.N1 + d1 * c.N2 + outV1 * c.N3;
+  s0 -= outV1 * c.BN1 + outV1 * c.BN2 + outV1 * c.BN3 + outV1 * c.BN4;
+  s1 -= s0 * c.D1 + outV1 * c.BN2 + outV1 * c.BN3 + outV1 * c.BN4;
+  s2 -= s1 * c.D1 + s0 * c.D2 + outV1 * c.BN3 + outV1 * c.BN4;
+  s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + outV1 * c.BN4;
+  causal[base] = s0; causal[base + st] = s1; causal[base + 2 * st] = s2; causal[base + 3 * st] = s3;
+  {
+    double dm1 = d3, dm2 = d2, dm3 = d1;                  // data[i-1], [i-2], [i-3]
+    double sm1 = s3, sm2 = s2, sm3 = s1, sm4 = s0;        // scratch[i-1] .. [i-4]
+    for (long long i = 4; i < ln; i++) {
+      const double di = D(i);
+      double si = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+      si -= sm1 * c.D1 + sm2 * c.D2 + sm3 * c.D3 + sm4 * c.D4;
+      causal[base + i * st] = si;
+      dm3 = dm2; dm2 = dm1; dm1 = di;
+      sm4 = sm3; sm3 = sm2; sm2 = sm1; sm1 = si;
+    }
+  }
+  const double outV2 = D(ln - 1);
+  const double e1 = D(ln - 1), e2 = D(ln - 2), e3 = D(ln - 3);
+  double t1 = outV2 * c.M1 + outV2 * c.M2 + outV2 * c.M3 + outV2 * c.M4;           // scratch[ln-1]
+  double t2 = e1 * c.M1 + outV2 * c.M2 + outV2 * c.M3 + outV2 * c.M4;              // [ln-2]
+  double t3 = e2 * c.M1 + e1 * c.M2 + outV2 * c.M3 + outV2 * c.M4;                 // [ln-3]
+  double t4 = e3 * c.M1 + e2 * c.M2 + e1 * c.M3 + outV2 * c.M4;                    // [ln-4]
+  t1 -= outV2 * c.BM1 + outV2 * c.BM2 + outV2 * c.BM3 + outV2 * c.BM4;
+  t2 -= t1 * c.D1 + outV2 * c.BM2 + outV2 * c.BM3 + outV2 * c.BM4;
+  t3 -= t2 * c.D1 + t1 * c.D2 + outV2 * c.BM3 + outV2 * c.BM4;
+  t4 -= t3 * c.D1 + t2 * c.D2 + t1 * c.D3 + outV2 * c.BM4;
+  auto put = [&](long long i, double anti) {
+    const double o = causal[base + i * st] + anti;        // outs[i] = causal; outs[i] += anti-causal
+    out[base + i * st] = (float)o;
+  };
+  put(ln - 1, t1); put(ln - 2, t2); put(ln - 3, t3); put(ln - 4, t4);
+  {
+    double dp0 = D(ln - 4), dp1 = e3, dp2 = e2, dp3 = e1; // data[i], [i+1], [i+2], [i+3] for i = ln-4
+    double sp0 = t4, sp1 = t3, sp2 = t2, sp3 = t1;        // scratch[i] .. [i+3]
+    for (long long i = ln - 4; i > 0; i--) {
+      double si = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+      si -= sp0 * c.D1 + sp1 * c.D2 + sp2 * c.D3 + sp3 * c.D4;
+      put(i - 1, si);
+      dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = D(i - 1);
+      sp3 = sp2; sp2 = sp1; sp1 = sp0; sp0 = si;
+    }
+  }
+}
+
+// component `dim` of the gradient image: the filtered float image over the spacing
+__global__ __launch_bounds__(256) void k_rg_store(const float *__restrict__ src, double *__restrict__ grad, int dim, double spacing,
+                                                  u64 nvox) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nvox) grad[3 * i + dim] = (double)src[i] / spacing;
+}
+// ImageBase::TransformLocalVectorToPhysicalVector on every pixel (double coordinates)
+__global__ __launch_bounds__(256) void k_rg_direction(double *__restrict__ grad, Geo geo, u64 nvox) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  const double l[3] = {grad[3 * i], grad[3 * i + 1], grad[3 * i + 2]};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double sum = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) sum += geo.dir[r * 3 + cc] * l[cc];
+    grad[3 * i + r] = sum;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2348,11 +2490,11 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
-  if (p.variant != CUBERILLE_PROJECT_DEFAULT)
+  if (p.variant != CUBERILLE_PROJECT_DEFAULT || p.gradVariant != 0)
     return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
       typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
       hipLaunchKernelGGL((k_project_variant<T>), dim3(grid_for(nPoints, 256, 0)), dim3(256), 0, s, (const T *)w.vox, g, geo, p,
-                         dirIdentity, w.points, nPoints, nGhost, w.totals);
+                         dirIdentity, w.points, nPoints, nGhost, w.totals, p.gradVariant ? w.gradImg : nullptr);
       return hipGetLastError();
     });
   // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms
@@ -2381,6 +2523,36 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
 #undef CUBERILLE_LAUNCH_PROJECT
     return hipGetLastError();
   });
+}
+
+// The recursive-Gaussian gradient image of the whole volume into w.gradImg (3 doubles per voxel), through the two float
+// volumes w.rgA / w.rgB and the double scratch volume w.rgScratch.  coef[dim][0]: the derivative filter along dim;
+// coef[ax][1]: the smoothing filter along ax (host: cuberille_api.hip, deriche_setup).
+hipError_t launch_recursive_gaussian(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const double coef[3][2][20],
+                                     hipStream_t s) {
+  const long long n[3] = {g.nx, g.ny, g.nzb};
+  const u64 nvox = (u64)g.nx * g.ny * g.nzb;
+  auto lines = [&](int axis) -> unsigned { return grid_for((u64)(nvox / (u64)n[axis]), 256, 0); };
+  auto coefOf = [&](int ax, int which) { DericheCoef c; std::memcpy(&c, coef[ax][which], sizeof(c)); return c; };
+  for (int dim = 0; dim < 3; dim++) {
+    hipError_t e = by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
+      typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+      hipLaunchKernelGGL((k_rg_pass<T>), dim3(lines(dim)), dim3(256), 0, s, (const T *)w.vox, w.rgA, w.rgScratch, coefOf(dim, 0),
+                         n[0], n[1], n[2], dim);
+      return hipGetLastError();
+    });
+    if (e != hipSuccess) return e;
+    float *src = w.rgA, *dst = w.rgB;
+    for (int ax = 0; ax < 3; ax++) {
+      if (ax == dim) continue;
+      hipLaunchKernelGGL((k_rg_pass<float>), dim3(lines(ax)), dim3(256), 0, s, (const float *)src, dst, w.rgScratch, coefOf(ax, 1),
+                         n[0], n[1], n[2], ax);
+      std::swap(src, dst);
+    }
+    hipLaunchKernelGGL(k_rg_store, dim3(grid_for(nvox, 256, 0)), dim3(256), 0, s, (const float *)src, w.gradImg, dim, geo.spacing[dim], nvox);
+  }
+  hipLaunchKernelGGL(k_rg_direction, dim3(grid_for(nvox, 256, 0)), dim3(256), 0, s, w.gradImg, geo, nvox);
+  return hipGetLastError();
 }
 
 }  // namespace cuberille

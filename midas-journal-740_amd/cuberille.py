@@ -77,10 +77,14 @@ SlabInfo = collections.namedtuple("SlabInfo", "alias_below lowest highest second
 PROJECT_DEFAULT, PROJECT_ADVANCED, PROJECT_LINESEARCH = 0, 1, 2    # include/cuberille_hip.h CUBERILLE_PROJECT_*
 
 
+GRADIENT_CENTRAL, GRADIENT_RECURSIVE_GAUSSIAN = 0, 1               # include/cuberille_hip.h CUBERILLE_GRADIENT_*
+
+
 def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50, q1=True,
-                variant=PROJECT_DEFAULT):
+                variant=PROJECT_DEFAULT, gradient=GRADIENT_CENTRAL):
     """variant picks the branch of ProjectVertexToIsoSurface: the shipped one (txx:439-474) or one of the two the
-    reference compiles out (USE_ADVANCED_PROJECTION txx:340-397, USE_LINESEARCH_PROJECTION txx:398-437; h:22-23)."""
+    reference compiles out (USE_ADVANCED_PROJECTION txx:340-397, USE_LINESEARCH_PROJECTION txx:398-437; h:22-23).
+    gradient: the shipped central differences, or USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21; txx:488-491; parity unpinned)."""
     # (the 64-bit integer pixel types take the iso value as an integer: a double cannot hold it past 2^53)
     iso_int = 0
     try:
@@ -90,7 +94,7 @@ def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, rel
         pass
     iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
     return _abi.Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                       float(relax), int(max_steps), int(bool(q1)), int(variant), 0, iso_int)
+                       float(relax), int(max_steps), int(bool(q1)), int(variant), int(gradient), iso_int)
 
 
 def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
@@ -368,6 +372,7 @@ class CuberilleImageToMeshFilter:
         self._max_steps = 50
         self._q1 = True
         self._variant = PROJECT_DEFAULT           # h:22-23: both alternative branches are compiled out
+        self._gradient = GRADIENT_CENTRAL         # h:21: and so is the recursive-Gaussian gradient
         self.last_result = None
 
     # h:184 / txx:53-56
@@ -452,6 +457,12 @@ class CuberilleImageToMeshFilter:
             raise ValueError("projection variant must be 0, 1 or 2")
         self._variant = int(variant)
 
+    def SetGradientVariant(self, gradient):
+        """Not in the reference's API: stands for building it with USE_GRADIENT_RECURSIVE_GAUSSIAN set (h:21)."""
+        if gradient not in (GRADIENT_CENTRAL, GRADIENT_RECURSIVE_GAUSSIAN):
+            raise ValueError("gradient variant must be 0 or 1")
+        self._gradient = int(gradient)
+
     def Update(self):
         if self._input is None:
             # the ITK pipeline throws for a missing required input (txx:33)
@@ -462,7 +473,7 @@ class CuberilleImageToMeshFilter:
         if self._step < 0.0:                      # txx:82-85, sticky like the reference (quirk Q3)
             self._step = max(vol.spacing) * 0.25
         prm = make_params(self._iso, self._triangles, self._project, self._threshold, self._step, self._relax,
-                          self._max_steps, self._q1, self._variant)
+                          self._max_steps, self._q1, self._variant, self._gradient)
         self.last_result = self._extractor.extract_host(vol, prm)
         self._output = self._extractor.download()
 

@@ -20,6 +20,11 @@
 #ifndef USE_LINESEARCH_PROJECTION
 #define USE_LINESEARCH_PROJECTION 0
 #endif
+// ... and h:21 fixes this one at 0 (itk::GradientImageFilter); 1: itk::GradientRecursiveGaussianImageFilter with
+// sigma = the largest spacing (txx:488-491), as cuberille_params::gradient_variant -- ITK's filter restated, parity unpinned
+#ifndef USE_GRADIENT_RECURSIVE_GAUSSIAN
+#define USE_GRADIENT_RECURSIVE_GAUSSIAN 0
+#endif
 
 #include "itkMacro.h"
 #include "itkMesh.h"

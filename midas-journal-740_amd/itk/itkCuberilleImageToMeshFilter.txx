@@ -383,11 +383,12 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   // same precedence as the reference's #if / #elif (txx:340,398)
   prm.projection_variant = USE_ADVANCED_PROJECTION ? CUBERILLE_PROJECT_ADVANCED
                          : (USE_LINESEARCH_PROJECTION ? CUBERILLE_PROJECT_LINESEARCH : CUBERILLE_PROJECT_DEFAULT);
-  prm.reserved = 0;
+  prm.gradient_variant = USE_GRADIENT_RECURSIVE_GAUSSIAN ? CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN : CUBERILLE_GRADIENT_CENTRAL;
   prm.iso_value_int = cuberille_detail::IsoInt<InputPixelType>::Get(m_IsoSurfaceValue);
-  if (hostWalk && m_ProjectVerticesToIsoSurface && prm.projection_variant != CUBERILLE_PROJECT_DEFAULT)
-    itkExceptionMacro(<< "USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION are only offered with the default "
-                         "LinearInterpolateImageFunction");
+  if (hostWalk && m_ProjectVerticesToIsoSurface &&
+      (prm.projection_variant != CUBERILLE_PROJECT_DEFAULT || prm.gradient_variant != CUBERILLE_GRADIENT_CENTRAL))
+    itkExceptionMacro(<< "USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION / USE_GRADIENT_RECURSIVE_GAUSSIAN are only "
+                         "offered with the default LinearInterpolateImageFunction");
 
   if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));

@@ -221,6 +221,126 @@ inline void normalize(float v[3]) {
   for (int k = 0; k < 3; k++) v[k] = (float)((double)v[k] / norm);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491), compiled out upstream: the gradient image comes from
+// itk::GradientRecursiveGaussianImageFilter with sigma = max spacing and NormalizeAcrossScale on.  The reference holds
+// three lines of it; everything else is ITK (3.x era), restated here from its published algorithm -- Deriche's
+// fourth-order recursive approximation of the Gaussian and its first derivative as ITK's
+// RecursiveGaussianImageFilter / RecursiveSeparableImageFilter run it (coefficient tables, the causal and anti-causal
+// recurrences with their constant-extension start-up, "boundary" coefficients, the float images between the passes,
+// the division by the spacing and the direction matrix at the end).  PARITY UNPINNED: no fixture of the reference
+// covers it and ITK cannot be built here; tests/test_oracle.py holds this to a second restatement in numpy.
+// ---------------------------------------------------------------------------------------------------------------
+struct Deriche {
+  double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
+};
+
+// RecursiveGaussianImageFilter::SetUp for order 0 (smoothing) or 1 (first derivative); sigma in physical units
+Deriche deriche_setup(double sigma, double spacing, int order, bool normalizeAcrossScale) {
+  static const double A1[3] = {1.3530, -0.6724, -1.3563}, B1[3] = {1.8151, -3.4327, 5.2318}, W1 = 0.6681, L1 = -1.3932;
+  static const double A2[3] = {-0.3531, 0.6724, 0.3446}, B2[3] = {0.0902, 0.6100, -2.2355}, W2 = 2.0787, L2 = -1.3732;
+  double direction = 1.0;
+  if (spacing < 0.0) { direction = -1.0; spacing = -spacing; }
+  const double sigmad = sigma / spacing;
+  Deriche c;
+  // ComputeDCoefficients
+  const double Cos1 = std::cos(W1 / sigmad), Cos2 = std::cos(W2 / sigmad), Exp1 = std::exp(L1 / sigmad), Exp2 = std::exp(L2 / sigmad);
+  c.D4 = Exp1 * Exp1 * Exp2 * Exp2;
+  c.D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+  c.D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+  c.D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+  c.D2 += Exp1 * Exp1 + Exp2 * Exp2;
+  c.D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  const double SD = 1.0 + c.D1 + c.D2 + c.D3 + c.D4;
+  const double DD = c.D1 + 2 * c.D2 + 3 * c.D3 + 4 * c.D4;
+  // ComputeNCoefficients
+  const double a1 = A1[order], b1 = B1[order], a2 = A2[order], b2 = B2[order];
+  const double Sin1 = std::sin(W1 / sigmad), Sin2 = std::sin(W2 / sigmad);
+  c.N0 = a1 + a2;
+  c.N1 = Exp2 * (b2 * Sin2 - (a2 + 2 * a1) * Cos2);
+  c.N1 += Exp1 * (b1 * Sin1 - (a1 + 2 * a2) * Cos1);
+  c.N2 = (a1 + a2) * Cos2 * Cos1;
+  c.N2 -= b1 * Cos2 * Sin1 + b2 * Cos1 * Sin2;
+  c.N2 *= 2 * Exp1 * Exp2;
+  c.N2 += a2 * Exp1 * Exp1 + a1 * Exp2 * Exp2;
+  c.N3 = Exp2 * Exp1 * Exp1 * (b2 * Sin2 - a2 * Cos2);
+  c.N3 += Exp1 * Exp2 * Exp2 * (b1 * Sin1 - a1 * Cos1);
+  const double SN = c.N0 + c.N1 + c.N2 + c.N3;
+  const double DN = c.N1 + 2 * c.N2 + 3 * c.N3;
+  bool symmetric;
+  if (order == 0) {
+    const double alpha0 = 2 * SN / SD - c.N0;
+    c.N0 /= alpha0; c.N1 /= alpha0; c.N2 /= alpha0; c.N3 /= alpha0;
+    symmetric = true;
+  } else {
+    const double across = normalizeAcrossScale ? sigma : 1.0;
+    double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    alpha1 *= direction;                          // a negative spacing negates the derivative's response
+    c.N0 *= across / alpha1; c.N1 *= across / alpha1; c.N2 *= across / alpha1; c.N3 *= across / alpha1;
+    symmetric = false;
+  }
+  // ComputeRemainingCoefficients
+  if (symmetric) {
+    c.M1 = c.N1 - c.D1 * c.N0; c.M2 = c.N2 - c.D2 * c.N0; c.M3 = c.N3 - c.D3 * c.N0; c.M4 = -c.D4 * c.N0;
+  } else {
+    c.M1 = -(c.N1 - c.D1 * c.N0); c.M2 = -(c.N2 - c.D2 * c.N0); c.M3 = -(c.N3 - c.D3 * c.N0); c.M4 = c.D4 * c.N0;
+  }
+  const double SN2 = c.N0 + c.N1 + c.N2 + c.N3, SM = c.M1 + c.M2 + c.M3 + c.M4, SD2 = 1.0 + c.D1 + c.D2 + c.D3 + c.D4;
+  c.BN1 = c.D1 * SN2 / SD2; c.BN2 = c.D2 * SN2 / SD2; c.BN3 = c.D3 * SN2 / SD2; c.BN4 = c.D4 * SN2 / SD2;
+  c.BM1 = c.D1 * SM / SD2; c.BM2 = c.D2 * SM / SD2; c.BM3 = c.D3 * SM / SD2; c.BM4 = c.D4 * SM / SD2;
+  return c;
+}
+
+// RecursiveSeparableImageFilter::FilterDataArray: one line of ln >= 4 samples, in double
+void deriche_line(const Deriche &c, const double *data, double *outs, double *scratch, idx_t ln) {
+  const double outV1 = data[0];                     // assumed to go on from the border to infinity
+  scratch[0] = outV1 * c.N0 + outV1 * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  scratch[1] = data[1] * c.N0 + outV1 * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  scratch[2] = data[2] * c.N0 + data[1] * c.N1 + outV1 * c.N2 + outV1 * c.N3;
+  scratch[3] = data[3] * c.N0 + data[2] * c.N1 + data[1] * c.N2 + outV1 * c.N3;
+  scratch[0] -= outV1 * c.BN1 + outV1 * c.BN2 + outV1 * c.BN3 + outV1 * c.BN4;
+  scratch[1] -= scratch[0] * c.D1 + outV1 * c.BN2 + outV1 * c.BN3 + outV1 * c.BN4;
+  scratch[2] -= scratch[1] * c.D1 + scratch[0] * c.D2 + outV1 * c.BN3 + outV1 * c.BN4;
+  scratch[3] -= scratch[2] * c.D1 + scratch[1] * c.D2 + scratch[0] * c.D3 + outV1 * c.BN4;
+  for (idx_t i = 4; i < ln; i++) {
+    scratch[i] = data[i] * c.N0 + data[i - 1] * c.N1 + data[i - 2] * c.N2 + data[i - 3] * c.N3;
+    scratch[i] -= scratch[i - 1] * c.D1 + scratch[i - 2] * c.D2 + scratch[i - 3] * c.D3 + scratch[i - 4] * c.D4;
+  }
+  for (idx_t i = 0; i < ln; i++) outs[i] = scratch[i];
+  const double outV2 = data[ln - 1];
+  scratch[ln - 1] = outV2 * c.M1 + outV2 * c.M2 + outV2 * c.M3 + outV2 * c.M4;
+  scratch[ln - 2] = data[ln - 1] * c.M1 + outV2 * c.M2 + outV2 * c.M3 + outV2 * c.M4;
+  scratch[ln - 3] = data[ln - 2] * c.M1 + data[ln - 1] * c.M2 + outV2 * c.M3 + outV2 * c.M4;
+  scratch[ln - 4] = data[ln - 3] * c.M1 + data[ln - 2] * c.M2 + data[ln - 1] * c.M3 + outV2 * c.M4;
+  scratch[ln - 1] -= outV2 * c.BM1 + outV2 * c.BM2 + outV2 * c.BM3 + outV2 * c.BM4;
+  scratch[ln - 2] -= scratch[ln - 1] * c.D1 + outV2 * c.BM2 + outV2 * c.BM3 + outV2 * c.BM4;
+  scratch[ln - 3] -= scratch[ln - 2] * c.D1 + scratch[ln - 1] * c.D2 + outV2 * c.BM3 + outV2 * c.BM4;
+  scratch[ln - 4] -= scratch[ln - 3] * c.D1 + scratch[ln - 2] * c.D2 + scratch[ln - 1] * c.D3 + outV2 * c.BM4;
+  for (idx_t i = ln - 4; i > 0; i--) {
+    scratch[i - 1] = data[i] * c.M1 + data[i + 1] * c.M2 + data[i + 2] * c.M3 + data[i + 3] * c.M4;
+    scratch[i - 1] -= scratch[i] * c.D1 + scratch[i + 1] * c.D2 + scratch[i + 2] * c.D3 + scratch[i + 3] * c.D4;
+  }
+  for (idx_t i = 0; i < ln; i++) outs[i] += scratch[i];
+}
+
+// one separable pass along `axis` over a whole volume: `get(i)` reads the input pixel (as a double), the result is
+// stored as float (the filter's internal images are float)
+template <class Get>
+void deriche_pass(const Geometry &g, const Deriche &c, int axis, Get get, float *out) {
+  const idx_t n[3] = {g.n[0], g.n[1], g.n[2]};
+  const idx_t stride[3] = {1, n[0], n[0] * n[1]};
+  const idx_t ln = n[axis];
+  const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+  std::vector<double> data(ln), outs(ln), scratch(ln);
+  for (idx_t v = 0; v < n[a2]; v++)
+    for (idx_t u = 0; u < n[a1]; u++) {
+      const idx_t base = u * stride[a1] + v * stride[a2];
+      for (idx_t i = 0; i < ln; i++) data[i] = get(base + i * stride[axis]);
+      deriche_line(c, data.data(), outs.data(), scratch.data(), ln);
+      for (idx_t i = 0; i < ln; i++) out[base + i * stride[axis]] = (float)outs[i];
+    }
+}
+
 // h:243-313: (x,y) -> point id, ordered by y then x (h:262-263).
 struct LookupNode {
   unsigned long x, y;
@@ -247,13 +367,85 @@ struct Filter {
   T iso;
   double step_length;
   std::vector<float> grad;           // ComputeGradientImage output, 3 floats per pixel
+  std::vector<double> gradD;         // ... of the recursive-Gaussian variant: CovariantVector<double,3> per pixel
   std::vector<float> points;
   std::vector<uint64_t> cells_flat;
   std::vector<std::unique_ptr<CellObj>> cells_heap;
   uint64_t iters = 0, stop_thr = 0, stop_steps = 0;
 
+  // GradientRecursiveGaussianImageFilter::GenerateData (ITK 3.x): per component `dim` the derivative filter along
+  // `dim` first, then the smoothing filters along the other axes in ascending order, float images in between; the
+  // result divided by the spacing of `dim`; the direction matrix applied to the vector at the end
+  void ComputeGradientImageRecursiveGaussian() {
+    const Geometry &g = im.g;
+    const size_t N = (size_t)g.n[0] * g.n[1] * g.n[2];
+    double sigma = g.spacing[0];                              // txx:489: m_MaxSpacing * 1.0
+    for (int i = 1; i < 3; i++) sigma = sigma > g.spacing[i] ? sigma : g.spacing[i];
+    gradD.assign(3 * N, 0.0);
+    std::vector<float> a(N), b(N);
+    for (int dim = 0; dim < 3; dim++) {
+      const Deriche dc = deriche_setup(sigma, g.spacing[dim], 1, true);       // txx:490: NormalizeAcrossScale
+      const T *px = im.px;
+      deriche_pass(g, dc, dim, [&](idx_t i) { return (double)px[i]; }, a.data());
+      float *src = a.data(), *dst = b.data();
+      for (int ax = 0; ax < 3; ax++) {
+        if (ax == dim) continue;
+        const Deriche sc = deriche_setup(sigma, g.spacing[ax], 0, true);
+        const float *in = src;
+        deriche_pass(g, sc, ax, [&](idx_t i) { return (double)in[i]; }, dst);
+        std::swap(src, dst);
+      }
+      for (size_t i = 0; i < N; i++) gradD[3 * i + dim] = (double)src[i] / g.spacing[dim];
+    }
+    for (size_t i = 0; i < N; i++) {                          // TransformLocalVectorToPhysicalVector
+      const double l[3] = {gradD[3 * i], gradD[3 * i + 1], gradD[3 * i + 2]};
+      for (int r = 0; r < 3; r++) {
+        double sum = 0.0;
+        for (int c = 0; c < 3; c++) sum += g.dir[r * 3 + c] * l[c];
+        gradD[3 * i + r] = sum;
+      }
+    }
+  }
+
+  // the normal at a point (txx:451-452 and its twins in the other branches), as a double vector for the step that
+  // follows.  Default gradient: CovariantVector<float,3> interpolated and normalised as I7 / I8 say; the recursive-
+  // Gaussian variant's GradientPixelType is CovariantVector<double,3>: interpolation and Normalize() stay in double
+  void NormalAt(const double p[3], double nd[3]) {
+    if (prm.gradient_variant == 1) {
+      double ci[3];
+      point_to_cindex(im.g, p, ci);
+      Cell8 c;
+      make_cell(im.g, ci, c);
+      double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+      for (unsigned counter = 0; counter < 8; counter++) {
+        double overlap = 1.0;
+        idx_t ni[3];
+        for (int k = 0; k < 3; k++) {
+          if (counter & (1u << k)) { ni[k] = c.hi[k]; overlap *= c.d[k]; }
+          else                     { ni[k] = c.lo[k]; overlap *= 1.0 - c.d[k]; }
+        }
+        if (overlap) {
+          const double *gp = &gradD[3 * ((ni[2] * im.g.n[1] + ni[1]) * im.g.n[0] + ni[0])];
+          for (int k = 0; k < 3; k++) acc[k] += overlap * gp[k];
+          total += overlap;
+        }
+        if (total == 1.0) break;
+      }
+      double sum = 0.0;
+      for (int k = 0; k < 3; k++) sum += acc[k] * acc[k];
+      const double norm = std::sqrt(sum);
+      for (int k = 0; k < 3; k++) nd[k] = acc[k] / norm;
+    } else {
+      float normal[3];
+      interpolate_gradient(im.g, grad.data(), p, normal);
+      normalize(normal);
+      for (int k = 0; k < 3; k++) nd[k] = (double)normal[k];
+    }
+  }
+
   // txx:478-498 (whole image, threads over z like ITK's ThreadedGenerateData)
   void ComputeGradientImage() {
+    if (prm.gradient_variant == 1) { ComputeGradientImageRecursiveGaussian(); return; }
     const Geometry &g = im.g;
     grad.resize((size_t)3 * g.n[0] * g.n[1] * g.n[2]);
     int nt = prm.gradient_threads > 0 ? prm.gradient_threads : 1;
@@ -276,18 +468,17 @@ struct Filter {
     double sign = 1.0;
     double step = step_length;
     unsigned int numberOfSteps = 0;
-    float normal[3];
+    double normal[3];
     while (!done) {
       iters++;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
-      interpolate_gradient(im.g, grad.data(), p, normal);                     // txx:451
-      normalize(normal);                                                      // txx:452
+      NormalAt(p, normal);                                                    // txx:451-452
       const double value = interpolate(im, p);                                // txx:455
       done |= std::fabs(value - (double)iso) < prm.distance_threshold;        // txx:456
       if (done) { stop_thr++; break; }                                        // txx:460
       sign = (value < (double)iso) ? +1.0 : -1.0;                             // txx:463
       for (int i = 0; i < 3; i++)                                             // txx:464-467 (I9)
-        vertex[i] = (float)((double)vertex[i] + ((double)normal[i] * sign * step));
+        vertex[i] = (float)((double)vertex[i] + (normal[i] * sign * step));
       step *= prm.relaxation;                                                 // txx:468
       done |= numberOfSteps++ > prm.max_steps;                                // txx:469
       if (done) stop_steps++;
@@ -308,12 +499,11 @@ struct Filter {
     while (!done) {
       iters++;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
-      float normal[3];
-      interpolate_gradient(im.g, grad.data(), p, normal);                     // txx:356
-      normalize(normal);                                                      // txx:357
+      double normal[3];
+      NormalAt(p, normal);                                                    // txx:356-357
       for (int k = 0; k < 3; k++) {                                           // txx:360-364
-        temp[0][k] = (float)((double)vertex[k] + ((double)normal[k] * +1.0 * step));
-        temp[1][k] = (float)((double)vertex[k] + ((double)normal[k] * -1.0 * step));
+        temp[0][k] = (float)((double)vertex[k] + (normal[k] * +1.0 * step));
+        temp[1][k] = (float)((double)vertex[k] + (normal[k] * -1.0 * step));
       }
       step *= prm.relaxation;                                                 // txx:365
       for (int e = 0; e < 2; e++) {                                           // txx:368-371
@@ -339,18 +529,18 @@ struct Filter {
   // Upstream leaves bestVertex uninitialised when no sample beats the initial 10000 (or there is no sample at all);
   // here the vertex then stays where it is.
   void ProjectVertexLineSearch(float vertex[3]) {
-    float normal[3], bestVertex[3] = {vertex[0], vertex[1], vertex[2]};
+    float bestVertex[3] = {vertex[0], vertex[1], vertex[2]};
+    double normal[3];
     double bestMetric = 10000;
     const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
-    interpolate_gradient(im.g, grad.data(), p, normal);                       // txx:408
-    normalize(normal);                                                        // txx:409
+    NormalAt(p, normal);                                                      // txx:408-409
     for (double sign = -1.0; sign <= 1.0; sign += 2.0) {                      // txx:412
       for (unsigned int j = 1; j < prm.max_steps / 2; j++) {                  // txx:415
         iters++;
         const double d = (double)j / ((double)prm.max_steps / 2.0);           // txx:418
         float temp[3];
         for (int k = 0; k < 3; k++)                                           // txx:419-422
-          temp[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step_length * d));
+          temp[k] = (float)((double)vertex[k] + (normal[k] * sign * step_length * d));
         const double q[3] = {(double)temp[0], (double)temp[1], (double)temp[2]};
         const double metric = std::fabs(interpolate(im, q) - (double)iso);    // txx:424-425
         if (metric < bestMetric) {                                            // txx:430-434
@@ -562,6 +752,9 @@ extern "C" {
 int cuberille_oracle_run(const oracle_image *img, const oracle_params *prm, oracle_mesh *out) {
   if (!valid_image(img) || !prm || !out) return 1;
   std::memset(out, 0, sizeof(*out));
+  if (prm->gradient_variant < 0 || prm->gradient_variant > 1) return 1;
+  if (prm->gradient_variant == 1 && prm->project_vertices)      // ITK: "the number of pixels along a direction must be >= 4"
+    for (int i = 0; i < 3; i++) if (img->dims[i] < 4) return 1;
   int err = 0;
   int rc = dispatch(img->pixel_type, [&](auto *tag) {
     typedef typename std::remove_pointer<decltype(tag)>::type T;

@@ -54,7 +54,9 @@ typedef struct {
   int32_t faithful_cells;        /* 1: one heap object per cell like txx:311,318,327 (cpu_baseline timing) */
   int32_t projection_variant;    /* 0: the default branch (txx:439-474); 1: USE_ADVANCED_PROJECTION (txx:340-397);
                                     2: USE_LINESEARCH_PROJECTION (txx:398-437) -- both compiled out upstream (h:22-23) */
-  int32_t reserved;
+  int32_t gradient_variant;      /* 0: itk::GradientImageFilter (what the reference ships, h:166); 1: USE_GRADIENT_RECURSIVE_GAUSSIAN
+                                    (h:21,163-164; txx:488-491): itk::GradientRecursiveGaussianImageFilter, sigma = max spacing,
+                                    NormalizeAcrossScale on -- compiled out upstream; restated from ITK 3.x, PARITY UNPINNED */
   int64_t iso_value_int;         /* ORACLE_PIX_I64 / _U64: the iso value itself (m_IsoSurfaceValue is an InputPixelType,
                                     h:180-181; a double cannot hold it past 2^53); _U64: the same 64 bits as unsigned */
 } oracle_params;

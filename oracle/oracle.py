@@ -29,7 +29,7 @@ class _Params(C.Structure):
     _fields_ = [("iso_value", C.c_double), ("generate_triangles", C.c_int32), ("project_vertices", C.c_int32),
                 ("distance_threshold", C.c_double), ("step_length", C.c_double), ("relaxation", C.c_double),
                 ("max_steps", C.c_uint32), ("gradient_threads", C.c_int32), ("faithful_cells", C.c_int32),
-                ("projection_variant", C.c_int32), ("reserved", C.c_int32), ("iso_value_int", C.c_int64)]
+                ("projection_variant", C.c_int32), ("gradient_variant", C.c_int32), ("iso_value_int", C.c_int64)]
 
 
 class _Mesh(C.Structure):
@@ -90,9 +90,10 @@ class OracleMesh:
 
 def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50,
         spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), gradient_threads=1,
-        faithful_cells=False, variant=0):
+        faithful_cells=False, variant=0, gradient=0):
     """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  variant: 0 the default projection,
-    1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches."""
+    1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches.  gradient: 0 the
+    central differences of itk::GradientImageFilter, 1 USE_GRADIENT_RECURSIVE_GAUSSIAN (compiled out upstream too)."""
     img, keep = _image(vol, spacing, origin, direction)
     iso_int = 0
     try:
@@ -102,7 +103,7 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
         pass
     iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
     prm = _Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), 0, iso_int)
+                  float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), int(gradient), iso_int)
     mesh = _Mesh()
     rc = lib().cuberille_oracle_run(C.byref(img), C.byref(prm), C.byref(mesh))
     if rc != 0:

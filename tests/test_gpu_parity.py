@@ -1470,23 +1470,27 @@ def test_extreme_aspect_ratios(pkg, oracle, extractor):
 
 
 def test_stage_timing_is_on_request(pkg, volumes):
-    """cuberille_result: ms_pass and ms_total are measured by every extraction; the five per-stage figures only with the
-    context's stage_timing switch (each event between two kernels costs the stream microseconds), 0 otherwise."""
-    vol = volumes("hydrogenAtom.mha")
-    prm = pkg.make_params(15, triangles=True, project=True)
+    """cuberille_result: ms_total is measured by every extraction, ms_pass by every extraction of more than 4 Mi voxels (a
+    smaller one gets ONE event pair: every event between two kernels costs the stream about as much as its kernels do);
+    the five per-stage figures only with the context's stage_timing switch, 0 otherwise."""
     ex = pkg.Extractor(0)
     stages = ("ms_classify", "ms_count", "ms_emit_points", "ms_project", "ms_emit_cells")
-    r = ex.extract_host(vol, prm)
-    assert r.ms_pass > 0 and r.ms_total > r.ms_pass
-    assert all(getattr(r, k) == 0.0 for k in stages)
-    ex.debug_option("stage_timing", 1)
-    r = ex.extract_host(vol, prm)
-    assert all(getattr(r, k) > 0.0 for k in stages)
-    assert abs(r.ms_classify + r.ms_count - r.ms_pass) < 0.02 * r.ms_pass + 0.005
-    assert abs(r.ms_pass + r.ms_emit_points + r.ms_project + r.ms_emit_cells - r.ms_total) < 0.02 * r.ms_total + 0.01
-    ex.debug_option("defaults", 0)
-    r = ex.extract_host(vol, prm)
-    assert all(getattr(r, k) == 0.0 for k in stages) and r.ms_pass > 0
+    prm = pkg.make_params(15, triangles=True, project=True)
+    big = np.zeros((160, 192, 192), dtype=np.uint8)                  # 5.9 M voxels
+    big[40:120, 50:140, 60:130] = 200
+    for vol, light in [(volumes("hydrogenAtom.mha"), True), (pkg.Volume(big), False)]:
+        for _ in range(2):                                          # (sized by a host read, then blind: both report alike)
+            r = ex.extract_host(vol, prm)
+            assert r.ms_total > 0 and (r.ms_pass == 0.0 if light else 0 < r.ms_pass < r.ms_total)
+            assert all(getattr(r, k) == 0.0 for k in stages)
+        ex.debug_option("stage_timing", 1)
+        r = ex.extract_host(vol, prm)
+        assert all(getattr(r, k) > 0.0 for k in stages)
+        assert abs(r.ms_classify + r.ms_count - r.ms_pass) < 0.02 * r.ms_pass + 0.005
+        assert abs(r.ms_pass + r.ms_emit_points + r.ms_project + r.ms_emit_cells - r.ms_total) < 0.02 * r.ms_total + 0.01
+        ex.debug_option("defaults", 0)
+        r = ex.extract_host(vol, prm)
+        assert all(getattr(r, k) == 0.0 for k in stages) and r.ms_total > 0
     ex.close()
 
 
@@ -1805,3 +1809,49 @@ def test_throwing_interpolator_leaves_through_update(tmp_path):
         r = subprocess.run([exe, "throw", str(tmp_path / "v.raw"), str(tmp_path / "s.raw"), "20", "0.0", str(threads)],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "caught: interpolator gave up" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_recursive_gaussian_gradient_matches_oracle(pkg, oracle, extractor, volumes, variant):
+    """cuberille_params::gradient_variant = RECURSIVE_GAUSSIAN (USE_GRADIENT_RECURSIVE_GAUSSIAN, h:21; txx:488-491: compiled
+    out upstream, ITK's Deriche filter restated -- parity unpinned against ITK, the oracle's restatement is held to a second
+    one in tests/test_oracle.py): the HIP gradient image + walk against the oracle, bit for bit, with each of the three
+    projection branches; data volumes, float fields, anisotropic spacing and a tilted direction matrix."""
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=30, variant=variant)
+    for name, iso in [("nucleon.mha", 140), ("fuel.mha", 15)]:
+        vol = volumes(name)
+        ref = oracle.run(vol.voxels, iso, gradient=1, **kw)
+        res = extractor.extract_host(vol, pkg.make_params(iso, gradient=1, **kw))
+        assert_same_mesh(extractor.download(), ref)
+        assert (int(res.proj_iterations), int(res.proj_stop_threshold), int(res.proj_stop_steps)) == \\
+            (ref.info["proj_iterations"], ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"])
+        plain = oracle.run(vol.voxels, iso, gradient=0, **kw)
+        assert not np.array_equal(plain.points, ref.points)             # it is another gradient
+    from restate import blend_field
+    fld, _ = blend_field(18)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    tilt = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    for dtype in (np.float32, np.float64, np.int16):
+        v = (fld * 40).astype(dtype)
+        for spacing, direction in [((1.0, 1.0, 1.0), np.eye(3)), ((0.5, 1.0, 2.0), np.eye(3)), ((0.7, 0.7, 1.3), tilt)]:
+            kw2 = dict(kw, threshold=0.5, step=0.2 * min(spacing))
+            geo = dict(spacing=spacing, origin=(3.0, -2.0, 0.5), direction=direction)
+            ref = oracle.run(v, 0, gradient=1, **kw2, **geo)
+            extractor.extract_host(pkg.Volume(v, spacing, geo["origin"], direction), pkg.make_params(0, gradient=1, **kw2))
+            assert_same_mesh(extractor.download(), ref)
+    # refused: a slab (the filter needs whole lines), fewer than 4 voxels along an axis, an unknown variant
+    import torch
+    vol = volumes("nucleon.mha")
+    nx, ny, nz = vol.dims
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    prm = pkg.make_params(140, gradient=1, **kw)
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.count(dev[:30].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, 30)), prm, pkg._abi.Slab(nz, 0, 0, 20, 0, 0))
+    assert e.value.code == pkg._abi.ERR_ARGUMENT
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.extract_host(pkg.Volume(np.zeros((3, 8, 8), dtype=np.uint8)), prm)
+    assert e.value.code == pkg._abi.ERR_ARGUMENT
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.extract_host(vol, pkg.make_params(140, gradient=2))
+    assert e.value.code == pkg._abi.ERR_ARGUMENT

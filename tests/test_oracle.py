@@ -292,3 +292,34 @@ def test_default_walk_restatement_matches_the_oracle(oracle):
         passes += n
         assert np.array_equal(np.asarray(want, dtype=np.float32).view(np.uint32), got.points[i].view(np.uint32)), i
     assert got.info["proj_iterations"] == passes
+
+
+def test_recursive_gaussian_gradient_against_second_restatement(oracle):
+    """USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491), compiled out upstream and with no fixture: the
+    oracle's restatement of ITK's recursive Gaussian gradient + the walk through it against a second restatement in
+    numpy (tests/restate.py): every projected vertex bit for bit, on unit and on anisotropic spacing.  PARITY UNPINNED
+    against ITK itself (oracle/cuberille_oracle.h)."""
+    from restate import py_default_walk_normal_fn, py_normal_from_gradient_image, recursive_gaussian_gradient
+    vol = _small_field()
+    for spacing in [(1.0, 1.0, 1.0), (0.5, 1.0, 2.0)]:
+        kw = dict(threshold=0.01, step=0.3 * min(spacing), relax=0.9, max_steps=14, spacing=spacing)
+        flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+        got = oracle.run(vol, 0.0, triangles=False, project=True, gradient=1, **kw)
+        plain = oracle.run(vol, 0.0, triangles=False, project=True, gradient=0, **kw)
+        assert not np.array_equal(got.points, plain.points)           # it is another gradient
+        grad = recursive_gaussian_gradient(vol, spacing)
+        passes = 0
+        for i, v in enumerate(flat.points):
+            want, n = py_default_walk_normal_fn(lambda p: py_normal_from_gradient_image(grad, p, spacing),
+                                                lambda p: oracle.interpolate(vol, p, spacing=spacing), 0.0, v,
+                                                kw["threshold"], kw["step"], kw["relax"], kw["max_steps"])
+            passes += n
+            assert np.array_equal(np.asarray(want, dtype=np.float32).view(np.uint32), got.points[i].view(np.uint32)), (spacing, i)
+        assert got.info["proj_iterations"] == passes
+    # a derivative filter: on a linear ramp the gradient is the slope, whatever the spacing (NormalizeAcrossScale
+    # multiplies by sigma; the walk only uses the direction)
+    z, y, x = np.meshgrid(*(np.arange(12, dtype=np.float64),) * 3, indexing="ij")
+    ramp = (2.0 * x + 3.0 * y - 1.0 * z).astype(np.float32)
+    g = recursive_gaussian_gradient(ramp)
+    mid = g[4:8, 4:8, 4:8]
+    assert np.allclose(mid[..., 0], 2.0, atol=1e-2) and np.allclose(mid[..., 1], 3.0, atol=1e-2) and np.allclose(mid[..., 2], -1.0, atol=1e-2)
