@@ -1823,7 +1823,7 @@ def test_recursive_gaussian_gradient_matches_oracle(pkg, oracle, extractor, volu
         ref = oracle.run(vol.voxels, iso, gradient=1, **kw)
         res = extractor.extract_host(vol, pkg.make_params(iso, gradient=1, **kw))
         assert_same_mesh(extractor.download(), ref)
-        assert (int(res.proj_iterations), int(res.proj_stop_threshold), int(res.proj_stop_steps)) == \\
+        assert (int(res.proj_iterations), int(res.proj_stop_threshold), int(res.proj_stop_steps)) == \
             (ref.info["proj_iterations"], ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"])
         plain = oracle.run(vol.voxels, iso, gradient=0, **kw)
         assert not np.array_equal(plain.points, ref.points)             # it is another gradient
