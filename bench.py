@@ -180,6 +180,9 @@ def main():
                     help="N>1: the count all-gather through the host (two more host waits per step) instead of device-resident rows")
     ap.add_argument("--opt", action="append", default=[],
                     help="development: name=value for cuberille_debug_set_option (kernel variants; results never depend on them)")
+    ap.add_argument("--partition", default="balanced", choices=["balanced", "uniform"],
+                    help="N>1: z-slabs of equal WORK, cut from the per-slice work a calibration step measures before the "
+                         "timed region (default), or of equal thickness")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="N=1: skip the extra measurement of one 1/8 slab (what a rank of an 8-GPU run does per step)")
     args = ap.parse_args()
@@ -251,6 +254,25 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = sh.extract(buf, prm)
+    partition = "uniform"
+    if world > 1 and strong and args.partition == "balanced":
+        # the surface of a volume is rarely spread evenly over z (this field's rippled sheet lies in a sixth of the
+        # slices): one calibration step on slabs of equal thickness measures what every slice costs, the slabs of the
+        # timed region are cut for equal work.  Outside the timed region, like any warm-up; the same volume, other cuts.
+        from midas_journal_740_amd.distributed import balanced_bounds
+        if res is None:
+            res = sh.extract(buf, prm)
+        bounds = balanced_bounds(sh.slice_work(res), world)
+        del buf
+        sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
+                              device_offsets=not args.host_offsets, bounds=bounds)
+        buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
+        buf[:sh.z0 - sh.lo].zero_()
+        buf[sh.z1 - sh.lo:].zero_()
+        torch.cuda.synchronize()
+        for _ in range(max(args.warmup, 2)):
+            res = sh.extract(buf, prm)
+        partition = "balanced"
     stage_keys = ["ms_classify", "ms_count", "ms_scan", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
     # the timed region carries the two event pairs every extraction has (the pass over the volume, the emit phase);
     # the per-stage events cost the stream about 8 us each and are switched on for a few extra extractions afterwards
@@ -317,7 +339,8 @@ def main():
         voxels = float(n) * n * gnz
         stages = {k: acc[k] / STAGE_REPS for k in stage_keys}
         # B_A = Nx*Ny*Nz*sizeof(pixel), every voxel this rank's launch reads counted once
-        alg_bytes = float(n) * n * (sh.hi - sh.lo) * np.dtype(dtype).itemsize
+        launch_slices = (sh.thi - sh.tlo) if (world > 1 and sh.thin) else (sh.hi - sh.lo)
+        alg_bytes = float(n) * n * launch_slices * np.dtype(dtype).itemsize
         classify_gbs = alg_bytes / (stages["ms_classify"] * 1e-3) / 1e9
         pass_ms = live["ms_pass"] / args.steps          # HIP events around the pass, every step of the timed region
         if pass_ms <= 0.0:                              # (volumes of a few M voxels get one event pair only: take the stage events)
@@ -341,6 +364,8 @@ def main():
                            n, n, sh.z1 - sh.z0, ("%d+%d" % sh.thin) if sh.thin else str(sh.halo if world > 1 else 0),
                            " (rest of the %d-slice halo on demand)" % sh.halo if sh.thin else ""),
                        "parallelism": "zslab%d" % world,
+                       "partition": partition + (" (slices per rank %s, cut for equal work from a calibration step before "
+                                                 "the timed region)" % [b - a for a, b in sh.bounds] if partition == "balanced" else ""),
                        "points": n_points, "cells": n_cells,
                        "projection_iterations_rank0": int(res.proj_iterations)},
             # the HBM-bound pass the north star's target is defined on: threshold sweep +

@@ -250,6 +250,10 @@ int cuberille_minimum_halo(const cuberille_image_desc *img, const cuberille_para
  * with the full halo.  cuberille_emit on a THIN_HALO slab refuses (CUBERILLE_ERR_HALO, the count stands) while walks wait. */
 int cuberille_escaped_count(cuberille_ctx *ctx, uint64_t *n_escaped);
 int cuberille_reproject_escaped(cuberille_ctx *ctx, const void *dev_voxels, int64_t z_begin, int64_t nz);
+/* Vertices created and quads emitted by every OWNED slice of the last count (n_slices = own_z1 - own_z0 entries each; a
+ * null array is skipped; waits for the stream).  For a driver that cuts a series of similar volumes into slabs of equal work
+ * rather than of equal thickness: the surface of a volume is rarely spread evenly over z. */
+int cuberille_slice_counts(cuberille_ctx *ctx, uint64_t *points, uint64_t *quads, size_t n_slices);
 /* After cuberille_count on a slab: see cuberille_slab_status. */
 int cuberille_slab_info(cuberille_ctx *ctx, cuberille_slab_status *out);
 

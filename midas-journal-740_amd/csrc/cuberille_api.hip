@@ -76,6 +76,7 @@ struct cuberille_ctx {
   bool haveHistory = false;
   u64 histV = 0, histQ = 0;
   u32 histVW = 0;
+  bool histDense = false;                // ... and whether a quarter or more of its words created vertices
   int stepMode = 0;                      // 0: no step open; 1: launched blindly (sizes on the device); 2: sized by a host read
   Totals *hostRows = nullptr;            // pinned: the gathered totals of all ranks, read back by cuberille_step_end
   size_t hostRowsCap = 0;
@@ -461,7 +462,10 @@ int count_launch(cuberille_ctx *c, const Gate &gate) {
   hipStream_t s = c->stream;
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   HIP_TRY(c, launch_occupancy(c->pixel_type, c->w, c->g, c->tune, s));
-  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, c->tune.count_variant, s));
+  // (the LDS-tiled form pays where most words carry surface -- 2048^3 noise -- and costs where few do: it stages every
+  //  row, a sparse block's untiled form skips whole words; the previous extraction's density decides)
+  const int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 1 : 0);
+  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, tiled, s));
   if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   return CUBERILLE_OK;
 }
@@ -768,6 +772,7 @@ int finish_result(cuberille_ctx *c, cuberille_result *res) {
   // what this extraction produced sizes the blind launches of the next cuberille_step_begin on this context
   c->haveHistory = true;
   c->histV = c->tot.totV; c->histQ = c->tot.totQ; c->histVW = c->tot.nVertexWords;
+  c->histDense = (u64)c->tot.nVertexWords * 4 >= (u64)c->nwords;
   c->stepMode = 0;
   c->haveMesh = true;
   c->counted = false;                        // the workspace now belongs to this mesh
@@ -1186,6 +1191,29 @@ int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, 
   rc = count_finish(c, &np, &nc);
   if (rc) return rc;
   return cuberille_emit(c, 0, res);
+}
+
+int cuberille_slice_counts(cuberille_ctx *c, uint64_t *points, uint64_t *quads, size_t n_slices) {
+  if (!c || (!points && !quads)) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no count on this context");
+  const int own = c->g.oz1 - c->g.oz0, counted = c->g.oz1 - c->g.cz0;
+  if (n_slices != (size_t)own) return fail(c, CUBERILLE_ERR_ARGUMENT, "one entry per owned slice, please");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // (scratch: the cell buffer is free between a count and its emit, but a mesh may be in it; a small buffer of its own)
+  DevBuf tmp;
+  HIP_TRY(c, tmp.reserve((size_t)(counted + 1) * 2 * sizeof(u64)));
+  std::vector<u64> host((size_t)(counted + 1) * 2);
+  hipError_t e = launch_slice_prefix(c->w, c->g, (u64 *)tmp.p, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), tmp.p, host.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  tmp.release();
+  if (e != hipSuccess) return fail(c, CUBERILLE_ERR_HIP, std::string("slice counts: ") + hipGetErrorString(e));
+  const int skip = c->g.oz0 - c->g.cz0;                       // the ghost slice
+  for (int z = 0; z < own; z++) {
+    if (points) points[z] = host[2 * (size_t)(z + skip + 1)] - host[2 * (size_t)(z + skip)];
+    if (quads) quads[z] = host[2 * (size_t)(z + skip + 1) + 1] - host[2 * (size_t)(z + skip) + 1];
+  }
+  return CUBERILLE_OK;
 }
 
 int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {

@@ -97,7 +97,8 @@ struct Tuning {
   int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
-  int count_variant = 1;      // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory
+  int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
+                              // the previous extraction on the context found vertices in a quarter of its words or more
   int cells_variant = 1;      // 1 a lane per quad (ships), 0 two phases per wave (a lane per word of the window, then a lane per quad: measured slower)
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
   int proj_f64cache = 0;      // 1 (float pixels): site gradients cached as doubles, three waves per SIMD
@@ -133,6 +134,7 @@ hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo,
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
                              const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, const Tuning &t,
                              hipStream_t s);
+hipError_t launch_slice_prefix(const Workspace &w, const Grid &g, u64 *out, hipStream_t s);
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
                               hipStream_t s);
 hipError_t launch_recursive_gaussian(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const double coef[3][2][20],

@@ -785,10 +785,19 @@ __global__ __launch_bounds__(NT, (TILED ? 4 : 5)) void k_count(const u64 *__rest
 #pragma unroll
         for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
         packed = (u32)nQ << 16;
-        if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
       }
     }
     cnt[i] = packed;
+    // the surface words of the wave take consecutive places in the queue: ONE LDS atomic per wave (an atomic per word,
+    // all on one address, is served one lane after the other: on a surface that touches most words that was a
+    // measurable part of this kernel)
+    const u64 m = __ballot(packed != 0u);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nQueued, (int)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (packed) queue[base + (int)__popcll(m & lowmask(lane))] = (unsigned short)i;
+    }
   }
   __syncthreads();
   const int nq = (MODE & 4) ? 0 : nQueued;
@@ -2455,6 +2464,33 @@ __global__ __launch_bounds__(256) void k_alias_plane(EmitArgs a, Grid g, int z, 
   }
   idsOut[j] = id;
   ptsOut[3 * j] = p[0]; ptsOut[3 * j + 1] = p[1]; ptsOut[3 * j + 2] = p[2];
+}
+
+// Vertices created / quads emitted before the first word of every counted slice (entry i: slice cz0 + i; the last
+// entry: the totals) -- what a driver that cuts the volume into slabs of equal WORK wants to know about the last count.
+__global__ __launch_bounds__(256) void k_slice_prefix(EmitArgs a, Grid g, size_t nwords, int nSlices, u64 *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nSlices) return;
+  const size_t gi = (size_t)i * g.ny * g.W;
+  u64 V, Q;
+  if (i < nSlices && gi < nwords) {
+    const u32 pw = a.prefix[gi];
+    V = seg_base<0>(a, gi) + (pw & 0xffffu);
+    Q = seg_base<16>(a, gi) + (pw >> 16);
+  } else {
+    V = a.tot->totV;
+    Q = a.tot->totQ;
+  }
+  out[2 * i] = V;
+  out[2 * i + 1] = Q;
+}
+
+hipError_t launch_slice_prefix(const Workspace &w, const Grid &g, u64 *out, hipStream_t s) {
+  const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
+  const EmitArgs a = emit_args(w, g, 0, 0);
+  const int nSlices = g.oz1 - g.cz0;
+  hipLaunchKernelGGL(k_slice_prefix, dim3(grid_for((u64)nSlices + 1, 256, 0)), dim3(256), 0, s, a, g, nwords, nSlices, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,

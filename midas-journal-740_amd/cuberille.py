@@ -241,6 +241,14 @@ class Extractor:
         self.result = res
         return res, True
 
+    def slice_counts(self, n_slices):
+        """(points, quads) created / emitted by every owned slice of the last count: two uint64 arrays."""
+        pts = np.empty(n_slices, dtype=np.uint64)
+        quads = np.empty(n_slices, dtype=np.uint64)
+        _abi.check(self._ctx, self._lib.cuberille_slice_counts(self._ctx, C.c_void_p(pts.ctypes.data),
+                                                                C.c_void_p(quads.ctypes.data), int(n_slices)))
+        return pts, quads
+
     def escaped_count(self):
         """THIN_HALO slabs, after emit_points(): walks that left the buffer (waits for the vertex phase)."""
         n = C.c_uint64()

@@ -43,13 +43,35 @@ def buffer_range(global_nz, z0, z1, halo=HALO):
     return max(z0 - below, 0), min(z1 + above, int(global_nz))
 
 
-def halo_transfers(global_nz, world, rank, halo=HALO, held=0):
+def balanced_bounds(work, world):
+    """Cut slices 0 .. len(work) into `world` contiguous slabs of (nearly) equal total work: [(z0, z1)] per rank, every
+    slab at least one slice.  work: a non-negative number per slice -- e.g. ShardedExtractor.slice_work() after a step on
+    a similar volume: the surface of a volume is rarely spread evenly over z, and a rank's time follows its surface."""
+    w = np.maximum(np.asarray(work, dtype=np.float64), 0.0)
+    nz = int(w.shape[0])
+    if world > nz:
+        raise ValueError("more ranks (%d) than slices (%d)" % (world, nz))
+    if not w.sum() > 0.0:
+        w = np.ones(nz)
+    acc = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        z = int(np.searchsorted(acc, acc[-1] * r / world, side="left"))
+        z = max(z, cuts[-1] + 1)                    # at least one slice each ...
+        z = min(z, nz - (world - r))                # ... and room for the ranks above
+        cuts.append(z)
+    cuts.append(nz)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def halo_transfers(global_nz, world, rank, halo=HALO, held=0, ranges=None):
     """The point-to-point transfers of one halo exchange as this rank sees them: (recvs, sends), each a list of
     (peer, z_first, z_last_exclusive) in global slices.  A rank needs [z0 - below, z0) and [z1, z1 + above) clipped to
     the volume; every slice of that comes from the rank that owns it -- the two neighbours when the slabs are at least
     `halo` thick, more ranks when they are thinner (thin slabs, long walks).  held: the part of the halo every rank has
     already (the thin halo of a first exchange): only what lies beyond it is moved."""
-    ranges = [slab_range(global_nz, world, r) for r in range(world)]
+    if ranges is None:
+        ranges = [slab_range(global_nz, world, r) for r in range(world)]
     bufs = [buffer_range(global_nz, a, b, halo) for a, b in ranges]
     have = [buffer_range(global_nz, a, b, held) for a, b in ranges]
 
@@ -73,13 +95,13 @@ def halo_transfers(global_nz, world, rank, halo=HALO, held=0):
     return recvs, sends
 
 
-def halo_bytes(global_nz, world, rank, slice_bytes, halo=HALO, held=0):
+def halo_bytes(global_nz, world, rank, slice_bytes, halo=HALO, held=0, ranges=None):
     """Bytes this rank receives in one halo exchange of that shape."""
-    recvs, _ = halo_transfers(global_nz, world, rank, halo, held)
+    recvs, _ = halo_transfers(global_nz, world, rank, halo, held, ranges)
     return sum(b - a for _, a, b in recvs) * int(slice_bytes)
 
 
-def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None, held=0):
+def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None, held=0, ranges=None):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry (and, held, that much halo
     around it).  Fills the rest of the halo (a number, or (below, above)) from the ranks that own those slices.  All
     ranks call it together.  wait=False (RCCL only): return the outstanding requests instead of waiting for them."""
@@ -87,7 +109,7 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo
     if buf.is_cuda and dist.get_backend(group) == "gloo" and wait:
         # rehearsal mode (several ranks sharing one GPU under gloo): stage the halos through the host
         host = buf.cpu()
-        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo, global_nz=global_nz, held=held)
+        exchange_halos(host, lo, hi, z0, z1, rank, world, group, halo=halo, global_nz=global_nz, held=held, ranges=ranges)
         buf.copy_(host)
         return buf
     if global_nz is None:
@@ -97,7 +119,7 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo
         sends = ([(rank + 1, z1 - min(h, z1 - z0), z1)] if rank < world - 1 and hi > z1 else []) + \
                 ([(rank - 1, z0, z0 + min(h, z1 - z0))] if rank > 0 and z0 > lo else [])
     else:
-        recvs, sends = halo_transfers(global_nz, world, rank, halo, held)
+        recvs, sends = halo_transfers(global_nz, world, rank, halo, held, ranges)
     ops, keep = [], []
     for peer, a, b in recvs:
         ops.append(dist.P2POp(dist.irecv, buf[a - lo:b - lo], peer, group))
@@ -232,7 +254,7 @@ class ShardedExtractor:
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
-                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True):
+                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
@@ -247,13 +269,20 @@ class ShardedExtractor:
         device_offsets (GPU buffers only): the step without a host round trip between count and emit
         (cuberille_step_begin / _end) -- the all-gather of the per-rank rows lands in device memory and the cell pass sums
         its id offset there; the host waits once per step.  A flag in any row (quirk Q1 across slabs, counts beyond the
-        sizes guessed from the previous step, an escaped walk) sends every rank through the synchronous protocol."""
+        sizes guessed from the previous step, an escaped walk) sends every rank through the synchronous protocol.
+        bounds: the ranks' slices [(z0, z1)] (contiguous, in rank order) instead of slabs of equal thickness -- e.g.
+        balanced_bounds(slice_work()) from a step on a similar volume."""
         from . import _abi
         from .cuberille import make_desc, minimum_halo, required_halo
         self.ex = extractor
         self.rank, self.world, self.group = rank, world, group
         self.nx, self.ny, self.nz = (int(v) for v in global_dims)
-        self.z0, self.z1 = slab_range(self.nz, world, rank)
+        self.bounds = [slab_range(self.nz, world, r) for r in range(world)] if bounds is None else \
+            [(int(a), int(b)) for a, b in bounds]
+        if len(self.bounds) != world or self.bounds[0][0] != 0 or self.bounds[-1][1] != self.nz or \
+                any(a >= b for a, b in self.bounds) or any(p[1] != q[0] for p, q in zip(self.bounds[:-1], self.bounds[1:])):
+            raise ValueError("bounds must cut slices 0 .. %d into %d contiguous, non-empty slabs" % (self.nz, world))
+        self.z0, self.z1 = self.bounds[rank]
         self._geo = (np_dtype, spacing, origin, direction)
         whole = make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction)
         if halo is None:
@@ -299,7 +328,8 @@ class ShardedExtractor:
         through two events (RCCL: the library runs on its own stream and thresholds the owned slices meanwhile)."""
         import torch
         import torch.distributed as dist
-        self.stats["halo_bytes"] += halo_bytes(self.nz, self.world, self.rank, self.nx * self.ny * self.itemsize, halo, held)
+        self.stats["halo_bytes"] += halo_bytes(self.nz, self.world, self.rank, self.nx * self.ny * self.itemsize, halo, held,
+                                               self.bounds)
         # (self.force_event_path: take the event branch under gloo too -- what the tests on one-GPU boxes set)
         if buf.is_cuda and (dist.get_backend(self.group) == "nccl" or self.force_event_path):
             if self._vox_event is None:
@@ -307,7 +337,7 @@ class ShardedExtractor:
                 self._halo_event = torch.cuda.Event()
             self._vox_event.record(torch.cuda.current_stream())
             reqs, keep = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
-                                        wait=False, halo=halo, global_nz=self.nz, held=held)
+                                        wait=False, halo=halo, global_nz=self.nz, held=held, ranges=self.bounds)
             for req in reqs:
                 req.wait()                     # orders torch's current stream behind the transfer, not the host
             self._halo_event.record(torch.cuda.current_stream())
@@ -315,7 +345,7 @@ class ShardedExtractor:
             slab.halo_ready_event = self._halo_event.cuda_event
             return keep
         exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=halo,
-                       global_nz=self.nz, held=held)
+                       global_nz=self.nz, held=held, ranges=self.bounds)
         if buf.is_cuda:
             torch.cuda.current_stream().synchronize()
             self.stats["host_syncs"] += 1
@@ -441,8 +471,7 @@ class ShardedExtractor:
         self._raise_if_any_failed(rows[:, ROW_FAILED], "cuberille_count", failed)
         # quirk Q1 across slab boundaries: rank r assumed that nothing is occupied below its buffer; a rank below says
         # otherwise.  Every rank derives the same plan from the gathered rows.
-        bounds = [slab_range(self.nz, self.world, r) for r in range(self.world)]
-        plan = alias_plan(rows, bounds) if self.check_aliasing else []
+        plan = alias_plan(rows, self.bounds) if self.check_aliasing else []
         if plan and not self.cross_slab_aliasing:
             raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % plan[0][0])
         if thin:
@@ -534,6 +563,32 @@ class ShardedExtractor:
         elif failed is not None:
             raise failed
         return res
+
+    def slice_work(self, result):
+        """After extract(): an estimate of the device time every slice of the volume cost, the same vector (float64,
+        one entry per global slice, milliseconds) on every rank -- from each rank's two measured intervals (the pass over
+        its voxels, the emit phase over its surface) spread over its slices by voxels and by vertices created.  Feed it to
+        balanced_bounds() to cut the next, similar volume into slabs of equal work.  (Two small collectives; not part
+        of a step.)"""
+        import torch
+        import torch.distributed as dist
+        own = self.z1 - self.z0
+        pts, _ = self.ex.slice_counts(own)
+        ms_pass, ms_emit = float(result.ms_pass), max(float(result.ms_total) - float(result.ms_pass), 0.0)
+        if ms_pass <= 0.0:                                       # (small volumes carry one interval only)
+            ms_pass, ms_emit = 0.25 * ms_emit, 0.75 * ms_emit
+        per_slice = np.full(own, ms_pass / own)
+        tot = float(pts.sum())
+        per_slice += ms_emit * (pts.astype(np.float64) / tot if tot > 0 else 1.0 / own)
+        work = np.zeros(self.nz, dtype=np.float64)
+        work[self.z0:self.z1] = per_slice
+        if self.world > 1:
+            t = torch.from_numpy(work)
+            if dist.get_backend(self.group) != "gloo":
+                t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            work = t.cpu().numpy()
+        return work
 
     def _raise_if_any_failed(self, flags, what, mine):
         if np.asarray(flags).any():

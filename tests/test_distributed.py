@@ -139,6 +139,44 @@ def test_halo_transfers_cover_the_halo_exactly():
                 assert (peer, r, a, b) in sent
 
 
+def test_balanced_bounds_and_their_halo_transfers():
+    """Slabs of equal work instead of equal thickness (the surface of a volume is rarely spread evenly over z): the
+    cuts, and the halo plan on such uneven slabs -- every halo slice still arrives exactly once, from its owner."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from midas_journal_740_amd import distributed as D
+    work = np.full(1024, 0.8)
+    work[430:594] += 10.0                                     # a sheet in a sixth of the slices (the bench's field)
+    for world in (2, 4, 8):
+        b = D.balanced_bounds(work, world)
+        assert b[0][0] == 0 and b[-1][1] == 1024 and all(p[1] == q[0] for p, q in zip(b[:-1], b[1:]))
+        loads = [work[a:c].sum() for a, c in b]
+        assert max(loads) < 1.06 * min(loads)
+        uniform = [work[a:c].sum() for a, c in (D.slab_range(1024, world, r) for r in range(world))]
+        assert world == 2 or max(uniform) > 1.6 * max(loads)      # (two ranks: the sheet is symmetric about the middle)
+    assert D.balanced_bounds(np.zeros(5), 5) == [(i, i + 1) for i in range(5)]          # nothing to go by: equal slabs
+    assert D.balanced_bounds([0, 0, 0, 100, 0, 0], 3) == [(0, 4), (4, 5), (5, 6)]        # every rank keeps a slice
+    with pytest.raises(ValueError):
+        D.balanced_bounds([1.0, 1.0], 3)
+    for bounds, halo in [([(0, 385), (385, 456), (456, 484), (484, 513), (513, 541), (541, 569), (569, 640), (640, 1024)], 8),
+                         ([(0, 3), (3, 4), (4, 20), (20, 22)], 8), ([(0, 30), (30, 33), (33, 40)], (3, 2))]:
+        nz, world = bounds[-1][1], len(bounds)
+        sent = set()
+        for r in range(world):
+            recvs, sends = D.halo_transfers(nz, world, r, halo, ranges=bounds)
+            z0, z1 = bounds[r]
+            lo, hi = D.buffer_range(nz, z0, z1, halo)
+            assert sorted(z for _, a, c in recvs for z in range(a, c)) == list(range(lo, z0)) + list(range(z1, hi))
+            for peer, a, c in recvs:
+                assert bounds[peer][0] <= a and c <= bounds[peer][1]
+            sent.update((r, peer, a, c) for peer, a, c in sends)
+        for r in range(world):
+            for peer, a, c in D.halo_transfers(nz, world, r, halo, ranges=bounds)[0]:
+                assert (peer, r, a, c) in sent
+
+
 def test_slab_plan():
     import sys
     sys.path.insert(0, ROOT)

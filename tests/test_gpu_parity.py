@@ -319,6 +319,18 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
             second = sh.extract(buf, prm)
             assert (int(second.n_points), int(second.n_cells), int(second.proj_iterations)) == keep
             stats.append(dict(sh.stats))
+        if mode == "step_balanced":
+            # slabs of equal work for the next volume of the series, cut from what this step measured per slice
+            from midas_journal_740_amd.distributed import balanced_bounds
+            work = sh.slice_work(second)
+            bounds = balanced_bounds(work, world)
+            assert abs(work.sum() - work[sh.z0:sh.z1].sum()) > 0 or world == 1
+            sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm,
+                                  thin_halo=True, device_offsets=True, bounds=bounds)
+            buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
+            buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()
+            sh.extract(buf, prm)
+            stats.append({"bounds": bounds})
         np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([repr(stats)]))
         m = ex.download()
         np.save(os.path.join(out_dir, "p%d.npy" % rank), m.points)
@@ -338,7 +350,7 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
 @pytest.mark.parametrize("world,event_path,step,mode,relax", [
     (2, False, 0.24, "sync", 0.95), (3, False, 0.24, "step", 0.95), (2, True, 0.24, "step", 0.95), (4, False, 0.5, "sync", 0.95),
     (3, False, 0.24, "thin", 0.95), (2, True, 0.24, "step_thin", 0.95), (4, False, 0.5, "step_thin", 0.95),
-    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0)])
+    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0), (4, False, 0.24, "step_balanced", 0.95)])
 def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step, mode, relax):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
@@ -367,7 +379,11 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
         assert all(st[0]["deep_halo_fetched"] == (relax == 1.0) for st in stats), stats
         if relax == 1.0:
             assert sum(st[0]["escaped"] for st in stats) > 0
-    if mode.startswith("step"):
+    if mode == "step_balanced":
+        # silicium's surface is spread unevenly over its 40 slices: the balanced cuts differ from 10-10-10-10
+        bounds = stats[0][-1]["bounds"]
+        assert all(st[-1]["bounds"] == bounds for st in stats) and [b - a for a, b in bounds] != [10, 10, 10, 10]
+    elif mode.startswith("step"):
         assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 2) for st in stats), stats
 
     class M:
