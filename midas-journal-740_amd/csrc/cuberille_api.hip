@@ -883,7 +883,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result 
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr,
-                               nullptr, 0, 0, 0, c->tune, s));
+                               nullptr, 0, 0, 0, s));
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   HIP_TRY(c, hipMemcpyAsync(c->hostTotals, w.totals, sizeof(Totals), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -971,7 +971,7 @@ int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank,
   if (blind || c->pointsEmitted) {
     const u64 nQ = blind ? c->histQ + c->histQ / 4 + 4096 : c->tot.totQ - c->tot.Q0;
     HIP_TRY(c, launch_emit_cells(c->w, c->g, c->prm.triangles, c->prm.q1, base, nQ, nullptr, (const Totals *)dev_rows, n_ranks, rank,
-                                 blind ? 1 : 0, c->tune, s));
+                                 blind ? 1 : 0, s));
   }
   HIP_TRY(c, hipEventRecord(c->ev[7], s));
   {
@@ -1236,7 +1236,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(cells_variant) OPT(count_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(proj_f64cache) OPT(stage_timing)
+  OPT(points_variant) OPT(count_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing)
 #undef OPT
   return false;
 }

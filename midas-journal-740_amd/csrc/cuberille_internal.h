@@ -99,9 +99,7 @@ struct Tuning {
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
                               // the previous extraction on the context found vertices in a quarter of its words or more
-  int cells_variant = 1;      // 1 a lane per quad (ships), 0 two phases per wave (a lane per word of the window, then a lane per quad: measured slower)
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
-  int proj_f64cache = 0;      // 1 (float pixels): site gradients cached as doubles, three waves per SIMD
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
 
@@ -132,8 +130,7 @@ hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, i
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
                               const Tuning &t, int dyn, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
-                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, const Tuning &t,
-                             hipStream_t s);
+                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s);
 hipError_t launch_slice_prefix(const Workspace &w, const Grid &g, u64 *out, hipStream_t s);
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
                               hipStream_t s);

@@ -72,9 +72,9 @@ template <int TT>
 __device__ __forceinline__ u32 bop3_32(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
 
 // inside-bits of the 16/sizeof(T) pixels of one 16-byte load: bit j = !(pixel j < iso)
-template <class T, bool SWAR_OLD = false>
+template <class T>
 __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
-  if constexpr (sizeof(T) == 1 && !SWAR_OLD) {
+  if constexpr (sizeof(T) == 1) {
     // 1-byte pixels, SWAR on the packed dwords.  Per byte, unsigned x >= t: with xl, tl the low 7 bits, bit 7 of
     // ((xl | 0x80) - tl) says xl >= tl (no borrow crosses bytes), and x >= t is (x7 | that) when t < 128, (x7 & that)
     // when t >= 128; signed pixels are biased by 0x80 first.  Three instructions per dword on v_bitop3 ((x & 0x7f..) |
@@ -96,26 +96,6 @@ __device__ __forceinline__ u32 inside_bits(const Vec16<T> &r, T iso) {
       acc[j >> 1] = __builtin_amdgcn_udot4(ge, (j & 1) ? 0x80402010u : 0x08040201u, acc[j >> 1], false);
     }
     return (acc[0] >> 7) | (acc[1] << 1);
-  } else if constexpr (sizeof(T) == 1) {
-    // 1-byte pixels, SWAR on the packed dwords (byte-wise extraction would blow the 16 bytes of every
-    // load up into 16 registers: 146 VGPRs and 3 waves per SIMD instead of 8).  Per byte, unsigned
-    // x >= t: with xl, tl the low 7 bits, bit 7 of ((xl | 0x80) - tl) says xl >= tl (no borrow crosses
-    // bytes), and x >= t is (x7 | that) when t < 128, (x7 & that) when t >= 128.  Signed pixels are
-    // biased by 0x80 first.  The four bit-7s are gathered into a nibble by one multiply.
-    const u32 bias = std::is_signed<T>::value ? 0x80808080u : 0u;
-    const u32 t = ((u32)(unsigned char)iso) ^ (bias & 0x80u);
-    const u32 tl = (t & 0x7fu) * 0x01010101u;
-    const bool thigh = (t & 0x80u) != 0;
-    const u32 w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
-    u32 m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const u32 x = w[j] ^ bias;
-      const u32 d = ((x & 0x7f7f7f7fu) | 0x80808080u) - tl;
-      const u32 ge = (thigh ? (x & d) : (x | d)) & 0x80808080u;
-      m |= ((((ge >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * j);
-    }
-    return m;
   } else {
     u32 m = 0;
 #pragma unroll
@@ -197,9 +177,7 @@ __device__ __forceinline__ u64 group_or(u64 part) {
 // write-through (sc1) stores in one burst; the grid is two workgroups per CU.
 constexpr int SPAN_WORDS = 4096;
 
-// VAR (development, cuberille::Tuning::classify_variant): 0 what ships; 2: the 1-byte pixels' older gather (32-bit
-// multiply); 3: the next trip's loads issued before this trip's arithmetic
-template <class T, int VAR = 0>
+template <class T>
 __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
                                                        double isoD, long long isoI, u32 *__restrict__ sliceOcc,
                                                        int lgWordsPerSlice) {
@@ -227,30 +205,17 @@ __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox
     auto pack = [&](const Vec16<T> (&r)[U], int tl) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const u32 m = inside_bits<T, VAR == 2>(r[u], iso);
+        const u32 m = inside_bits<T>(r[u], iso);
         const u64 word = group_or<LPW>((u64)m << (sub * VPL));
         if (last) stage[(tl * U + u) * VPL + lane / LPW] = word;
       }
     };
-    if constexpr (VAR == 3) {
-      Vec16<T> r[U], nx[U];
-      load(r, wib);
 #pragma unroll 1
-      for (int i = 0; i < TRIPS; i++) {
-        const int tl = i * 4 + wib;                      // the waves take the span's trips in turn
-        if (i + 1 < TRIPS) load(nx, tl + 4);
-        pack(r, tl);
-#pragma unroll
-        for (int u = 0; u < U; u++) r[u].raw = nx[u].raw;
-      }
-    } else {
-#pragma unroll 1
-      for (int i = 0; i < TRIPS; i++) {
-        const int tl = i * 4 + wib;                      // the waves take the span's trips in turn
-        Vec16<T> r[U];
-        load(r, tl);
-        pack(r, tl);
-      }
+    for (int i = 0; i < TRIPS; i++) {
+      const int tl = i * 4 + wib;                        // the waves take the span's trips in turn
+      Vec16<T> r[U];
+      load(r, tl);
+      pack(r, tl);
     }
     __syncthreads();
     const u64 w0 = sp * (u64)SPAN_WORDS;
@@ -944,7 +909,6 @@ struct EmitArgs {
   const Totals *rows;  // cuberille_step_end: the gathered totals of all ranks (device memory), or null
   int nRanks, rank;    //   -> this rank's point id offset = owned points of the ranks below; any flag on any rank: no cells
   int dyn;             // the launch was sized blindly (cuberille_step_begin): sizes from `tot`, and only when tot->go
-  int noTwoPhase;      // development switch (Tuning::cells_variant 1): the one-lane-per-quad search of round 2
 };
 
 // absolute exclusive prefix (SHIFT 0: vertices, 16: quads) at the start of the segment that holds word gi
@@ -1347,73 +1311,6 @@ __device__ __forceinline__ bool locate_quad(const EmitArgs &a, const Grid &g, si
   return true;
 }
 
-// The same in two phases per wave (the shape of k_emit_points_dense).  The wave's 64 outputs come from a short run of
-// words that starts at head[first / 64].  Phase 1, one lane per WORD of a 64-word window: its absolute prefix says
-// which outputs it produces; it forms its six face masks once and walks its quads in order (voxel, then face, as
-// txx:197-202 emits them), writing a 2-byte descriptor (source lane, voxel, face) for every output that falls into the
-// wave's range.  Phase 2, one lane per QUAD: descriptor -> voxel and face.  The six face masks are formed once per word
-// instead of once per quad, and the search for the r-th face bit (six popcounts at each of six levels, on every lane)
-// is gone.  Windows slide while outputs stay uncovered (sparse surfaces); what four windows do not cover is searched
-// for per lane as before.  Returns whether this lane's quad was found.  All 64 lanes call this together.
-__device__ __forceinline__ bool locate_quads_wave(const EmitArgs &a, const Grid &g, size_t nwords, unsigned short *qdesc, u64 q,
-                                                  bool valid, u64 Q0, int &x, int &y, int &z, int &f) {
-  const int lane = threadIdx.x & 63;
-  const u64 first = __shfl(q + Q0, 0, 64);       // lane 0 is always valid; a multiple of 64
-  size_t w0 = a.headQ[first >> 6];
-  qdesc[lane] = 0xffffu;
-  bool found = false;
-  for (int slide = 0; slide < 4; slide++) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const size_t w = w0 + lane;
-    if (w < nwords) {
-      const u64 A = seg_base<16>(a, w) + ((a.prefix[w] >> 16) & 0xffffu);
-      const long long rel = (long long)(A - first);          // first output of word w relative to the wave's first
-      if (rel < 64) {                                        // (the head word starts at most one word's worth below 0)
-        int wk, wy, wz;
-        word_coords(g, w, wk, wy, wz);
-        if (a.bits[((size_t)wz * g.ny + wy) * g.W + wk] != 0) {
-          u64 F[6];
-          faces_word(a.bits, g, wy, wz, wk, F);
-          u64 any = F[0] | F[1] | F[2] | F[3] | F[4] | F[5];
-          int o = (int)rel;
-          while (any && o < 64) {
-            const int bx = __ffsll((long long)any) - 1;
-            any &= any - 1;
-            unsigned fm = 0;
-#pragma unroll
-            for (int ff = 0; ff < 6; ff++) fm |= (unsigned)((F[ff] >> bx) & 1ull) << ff;
-            while (fm && o < 64) {
-              const int ff = __ffs((int)fm) - 1;
-              fm &= fm - 1;
-              if (o >= 0) qdesc[o] = (unsigned short)((lane << 9) | (bx << 3) | ff);
-              o++;
-            }
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned d = qdesc[lane];
-    if (valid && !found && d != 0xffffu) {
-      int k;
-      word_coords(g, w0 + (d >> 9), k, y, z);
-      x = k * 64 + (int)((d >> 3) & 63u);
-      f = (int)(d & 7u);
-      found = true;
-      qdesc[lane] = 0xfffeu;                                 // taken: a later window leaves it alone
-    }
-    if (!__ballot(valid && !found)) break;
-    // (a descriptor written in a later window for an output found already cannot happen: outputs are monotone in the
-    //  words, and a window only writes outputs its words produce)
-    w0 += 64;
-  }
-  return found;
-}
-
 // a wave's NV ids per quad are 32 or 48 contiguous bytes per lane, 2 or 3 KiB per wave: staged through LDS so that the
 // wave writes them as whole 16-byte lanes side by side instead of 64 strided 8-byte pieces per store
 template <int NV>
@@ -1442,7 +1339,6 @@ template <bool TRI, bool MAP>
 __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t nwords, u64 nQ) {
   constexpr int NV = TRI ? 6 : 4;                // ids per quad
   __shared__ u64 stage[4][64 * NV];
-  __shared__ unsigned short qdesc[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const u64 waveFirst = q - lane;
@@ -1464,19 +1360,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
   }
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
   int x, y, z, f;
-  bool have = false;
-  const bool valid = q < nQ;
-  if (a.headQ && (Q0 & 63) == 0 && !a.noTwoPhase) {
-    have = locate_quads_wave(a, g, nwords, qdesc[wv], q, valid, Q0, x, y, z, f);
-    if (valid && !have) {                          // beyond four windows: the per-lane search through the prefix levels
-      EmitArgs b = a;
-      b.headQ = nullptr;
-      have = locate_quad(b, g, nwords, q, true, Q0, x, y, z, f);
-    }
-  } else {
-    have = locate_quad(a, g, nwords, q, valid, Q0, x, y, z, f);
-  }
-  if (have) {
+  if (locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f)) {
     u64 lid[4], o[NV];
     quad_corners<MAP>(a, g, x, y, z, f, lid);
     finish_cell<TRI>(a, V0, totV, lid, o);
@@ -1733,10 +1617,8 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // the escape list untouched and is walked again from its start once the deeper halo is there (MODE 2: the vertices
 // are taken from that list; `g` then describes the deeper buffer).  dyn (cuberille_step_begin): the launch was sized
 // blindly, the real counts are read from `tot`.
-// F64C (development, Tuning::proj_f64cache; round-3 review item 5): the cached site gradients held as doubles -- the 24
-// conversions happen once per gather instead of once per pass -- at the price of the fourth wave per SIMD.
-template <class T, int MODE, bool F64C = false>
-__global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+template <class T, int MODE>
+__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
                                                  int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
                                                  u32 *__restrict__ escList, u32 escCap, int dyn) {
@@ -1779,7 +1661,6 @@ __global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__rest
   unsigned numberOfSteps = 0;
   int kc[3] = {-2, -2, -2};                        // cell held in registers, named by its clamped floor indices
   float G[8][3];
-  double Gd[F64C ? 8 : 1][3];
   typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
   bool unitP2I = true;
@@ -1841,15 +1722,6 @@ __global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__rest
         }
         cellFinite = (tf == 0.0f) && (td == 0.0);
         if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);   // rare: the reference's formula to the letter
-        if (F64C) {
-#pragma unroll
-          for (int counter = 0; counter < 8; counter++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              Gd[counter][k] = (double)G[counter][k];
-              asm volatile("" : "+v"(Gd[counter][k]));       // (or the compiler keeps the floats and converts at every use)
-            }
-        }
       }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
       // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite
@@ -1879,7 +1751,7 @@ __global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__rest
 #pragma unroll
         for (int counter = 0; counter < 8; counter++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (F64C ? Gd[F64C ? counter : 0][k] : (double)G[counter][k]);
+          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
           value += o[counter] * (double)Vd[counter];
         }
       } else {
@@ -1888,7 +1760,7 @@ __global__ __launch_bounds__(256, (F64C ? 3 : 4)) void k_project(const T *__rest
         for (int counter = 0; counter < 8; counter++) {
           if (o[counter] != 0.0 && total != 1.0) {   // "if (overlap)" + "break once total == 1"
 #pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (F64C ? Gd[F64C ? counter : 0][k] : (double)G[counter][k]);
+            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
             value += o[counter] * (double)Vd[counter];
             total += o[counter];
           }
@@ -2322,16 +2194,11 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       // large ranges: whole spans through the staged write-through kernel (below ~256 MiB the caches absorb the
       // word stores and more, smaller workgroups fill the chip better)
       u64 spanWords = 0;
-      if (tn.classify_variant != 1 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
+      if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
         const u64 nspans = nwordsAll / SPAN_WORDS;
         const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU
         const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
-        if (tn.classify_variant == 2)
-          hipLaunchKernelGGL((k_classify_span<T, 2>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
-        else if (tn.classify_variant == 3)
-          hipLaunchKernelGGL((k_classify_span<T, 3>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
-        else
-          hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
+        hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
         spanWords = nspans * SPAN_WORDS;
       }
       const u64 restWords = nwordsAll - spanWords;
@@ -2413,7 +2280,7 @@ static EmitArgs emit_args(const Workspace &w, const Grid &g, int q1, u64 pointOf
   a.cmap = w.cmap;
   a.headV = w.headV; a.headQ = w.headQ;
   a.extIds = nullptr;
-  a.rows = nullptr; a.nRanks = 0; a.rank = 0; a.dyn = 0; a.noTwoPhase = 0;
+  a.rows = nullptr; a.nRanks = 0; a.rank = 0; a.dyn = 0;
   return a;
 }
 
@@ -2502,14 +2369,12 @@ hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64
 }
 
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
-                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, const Tuning &tn,
-                             hipStream_t s) {
+                             const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s) {
   if (!nQ) return hipSuccess;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   EmitArgs a = emit_args(w, g, q1, pointOffset);
   a.extIds = extIds;
   a.rows = rows; a.nRanks = nRanks; a.rank = rank; a.dyn = dyn;
-  a.noTwoPhase = tn.cells_variant == 1;
   const dim3 grid(grid_for(nQ, 256, 0)), block(256);
   if (triangles && a.cmap) hipLaunchKernelGGL((k_emit_cells<true, true>), grid, block, 0, s, a, g, nwords, nQ);
   else if (triangles) hipLaunchKernelGGL((k_emit_cells<true, false>), grid, block, 0, s, a, g, nwords, nQ);
@@ -2551,10 +2416,6 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
                        w.escCap, dyn)
     if (mode == 1) CUBERILLE_LAUNCH_PROJECT(1);
     else if (mode == 2) CUBERILLE_LAUNCH_PROJECT(2);
-    else if (tn.proj_f64cache && std::is_same<T, float>::value)
-      hipLaunchKernelGGL((k_project<float, 0, true>), dim3(blocks), dim3(256), 0, s, (const float *)w.vox, g, geo, p, dirIdentity,
-                         w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,
-                         w.escCap, dyn);
     else CUBERILLE_LAUNCH_PROJECT(0);
 #undef CUBERILLE_LAUNCH_PROJECT
     return hipGetLastError();
