@@ -12,15 +12,21 @@
 //   count    : per block of 2048 words: face masks for every word, then one lane per word that has a
 //              face: 3-input boolean algebra (v_bitop3) over the 27 neighbour bit-rows gives the 8 "this
 //              voxel creates corner i" masks; popcounts + a wavefront scan per 64-word segment + a scan
-//              over the block's 32 segments; block totals are published with agent-scope atomics and the
-//              LAST block to arrive scans them (no separate scan launches)       -> prefix, segPre, blockBase
+//              over the block's 32 segments; the words that create vertices go to a queue, in order (ballots);
+//              where most words carry surface the bit rows are read from an LDS tile
+//   scan     : k_block_scan, one workgroup: block totals -> absolute bases, grand totals (and, for a step
+//              launched blindly, the go/no-go for the launches behind it)            -> prefix, segPre, blockBase
 //   emit     : points: one lane per vertex-creating word writes descriptors into LDS, then one lane per
 //              vertex; cells: one lane per output quad, located by a per-wave search of the prefix
 //              arrays, ids staged through LDS; everything lands at its final, reference-order index;
-//              corner ids through a dense lattice-corner map
+//              corner ids through a dense lattice-corner map; a rank's id offset from the gathered rows of
+//              all ranks when the step runs without the host in between
 //   project  : refilling waves, the damped gradient walk with the gradient image evaluated on the
 //              fly (never materialised); runs between the point and the cell pass so that the
-//              shorter-diagonal triangle split is fused into the cell pass.
+//              shorter-diagonal triangle split is fused into the cell pass.  On a THIN_HALO slab a walk that
+//              wants a slice the buffer lacks is put aside and walked again once the slice is there.
+//              Plain lane-per-vertex kernels for the reference's compiled-out variants (the two other
+//              projection branches, the recursive-Gaussian gradient image).
 // Bit-exactness of the floating-point part against the CPU oracle relies on
 // -ffp-contract=off (no FMA fusion; the explicit fma calls in the walk are the compiler's own f64
 // sqrt / division sequences written out) and IEEE f64 arithmetic; see csrc/Makefile.

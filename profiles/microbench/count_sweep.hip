@@ -1,6 +1,8 @@
-// Development harness (not part of the product library): the count + scan kernel on the bench volume, after either
-// flavour of the sweep, timed alone (HIP events around the one launch).
+// Development harness (not part of the product library): the count + scan kernel alone (HIP events around the one
+// launch) on a synthetic uint8 field whose surface density is a parameter, untiled and LDS-tiled, with parts of the
+// kernel switched off (MODE bits: 2 stop before the block-level scans and the vertex-word queue, 4 no corner logic).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o count_sweep count_sweep.hip
+//   ./count_sweep [n=1024] [wavelength=48] [reps=10]
 #include "../../midas-journal-740_amd/csrc/cuberille_kernels.hip"
 
 #include <cstdio>
@@ -10,29 +12,27 @@
 using namespace cuberille;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-__global__ void k_fill_ml(float *vox, int n) {
+// blobs of about `wl` voxels: 128 + 42 (sin + sin + sin), a little hashed roughness
+__global__ void k_fill(unsigned char *vox, int n, float wl) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n * n * n;
   if (i >= total) return;
   const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
-  float v = 0.f;
-  if (x >= 1 && x <= n - 2 && y >= 1 && y <= n - 2 && z >= 1 && z <= n - 2) {
-    const double m = n - 2;
-    const double X = -1.0 + (2.0 * (x - 1.0) + 1.0) / m, Y = -1.0 + (2.0 * (y - 1.0) + 1.0) / m, Z = -1.0 + (2.0 * (z - 1.0) + 1.0) / m;
-    const double r = sqrt(X * X + Y * Y);
-    const double pr = cos(2.0 * M_PI * 6.0 * cos(M_PI * r / 2.0));
-    v = (float)(((1.0 - sin(M_PI * Z / 2.0)) + 0.25 * (1.0 + pr)) / (2.0 * 1.25));
-  }
-  vox[i] = v;
+  const float k = 6.2831853f / wl;
+  unsigned h = (unsigned)i * 2654435761u;
+  h ^= h >> 15;
+  const float v = 128.f + 42.f * (sinf(k * x) + sinf(1.13f * k * y + 1.f) + sinf(0.91f * k * z + 2.f)) + (float)(h & 7u) - 3.5f;
+  vox[i] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
 }
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1024;
-  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const float wl = argc > 2 ? (float)atof(argv[2]) : 48.f;
+  const int reps = argc > 3 ? atoi(argv[3]) : 10;
   const size_t nvox = (size_t)n * n * n;
-  float *vox;
-  CK(hipMalloc(&vox, nvox * 4));
-  hipLaunchKernelGGL(k_fill_ml, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, 0, vox, n);
+  unsigned char *vox;
+  CK(hipMalloc(&vox, nvox));
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, 0, vox, n, wl);
   CK(hipDeviceSynchronize());
   Grid g{};
   g.nx = g.ny = g.nzb = n; g.W = n / 64; g.lastpos = 63;
@@ -42,73 +42,47 @@ int main(int argc, char **argv) {
   const size_t nwords = nvox / 64, nseg = nwords / 64, nblk = (nwords + COUNT_WB - 1) / COUNT_WB;
   Workspace w{};
   w.vox = vox;
-  CK(hipMalloc(&w.bits, nwords * 8)); CK(hipMalloc(&w.sliceOcc, n * 4)); CK(hipMalloc(&w.prefix, nwords * 4));
+  CK(hipMalloc(&w.bits, (nwords + (size_t)n * g.W) * 8)); CK(hipMalloc(&w.sliceOcc, n * 4)); CK(hipMalloc(&w.prefix, nwords * 4));
   CK(hipMalloc(&w.segPre, nseg * 8)); CK(hipMalloc(&w.blockTot, nblk * 8)); CK(hipMalloc(&w.blockBase, nblk * 16));
   CK(hipMalloc(&w.totals, sizeof(Totals))); CK(hipMalloc(&w.vqueue, nwords * 4));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   Tuning tn;
-  for (int variant = 0; variant < 2; variant++) {
-    tn.classify_variant = variant;
-    std::vector<float> tc, tk;
+  Params prm{};
+  prm.iso = 128.0;
+  CK(hipMemsetAsync(w.sliceOcc, 0, n * 4, 0));
+  CK(launch_classify(CUBERILLE_PIX_U8, w, g, prm, 0, n, tn, 0));
+  CK(hipDeviceSynchronize());
+  const unsigned blocks = (unsigned)nblk;
+  auto timeIt = [&](auto launch, const char *what) {
+    std::vector<float> tk;
     Totals t{};
-    for (int i = 0; i < reps + 2; i++) {
-      CK(hipMemsetAsync(w.sliceOcc, 0, n * 4, 0));
+    for (int i = 0; i < reps + 1; i++) {
       CK(hipMemsetAsync(w.totals, 0, sizeof(Totals), 0));
       CK(hipEventRecord(a, 0));
-      CK(launch_classify(CUBERILLE_PIX_F32, w, g, 0.5, 0, n, tn, 0));
+      launch();
       CK(hipEventRecord(b, 0));
       CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
-      if (i >= 2) tc.push_back(ms);
-      CK(hipEventRecord(a, 0));
-      CK(launch_count(w, g, nwords, 1, 0));
-      CK(hipEventRecord(b, 0));
-      CK(hipEventSynchronize(b));
-      CK(hipEventElapsedTime(&ms, a, b));
-      if (i >= 2) tk.push_back(ms);
-      CK(hipMemcpy(&t, w.totals, sizeof(Totals), hipMemcpyDeviceToHost));
+      if (i) tk.push_back(ms);
     }
-    std::sort(tc.begin(), tc.end()); std::sort(tk.begin(), tk.end());
-    printf("classify variant %d: classify %.4f ms  count %.4f ms   totV %llu totQ %llu vertexWords %u\n", variant,
-           tc[tc.size() / 2], tk[tk.size() / 2], t.totV, t.totQ, t.nVertexWords);
-  }
-  // parts of the kernel switched off: 1 no last-block scan, 2 no publish either, 4 no corner logic (phase 2), 6 = 2 + 4
-  auto timeMode = [&](auto tag, const char *what) {
-    constexpr int MODE = decltype(tag)::value;
-    std::vector<float> tk;
-    const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
-    for (int i = 0; i < reps; i++) {
-      CK(hipMemsetAsync(w.totals, 0, sizeof(Totals), 0));
-      CK(hipEventRecord(a, 0));
-      hipLaunchKernelGGL(k_count<MODE>, dim3(blocks), dim3(256), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, w.prefix, w.segPre, w.blockTot,
-                         w.vqueue, w.totals);
-      CK(hipEventRecord(b, 0));
-      CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b));
-      tk.push_back(ms);
-    }
+    CK(hipMemcpy(&t, w.totals, sizeof(Totals), hipMemcpyDeviceToHost));
     std::sort(tk.begin(), tk.end());
-    printf("count mode %d (%s): %.4f ms\n", MODE, what, tk[tk.size() / 2]);
+    printf("%-58s %.4f ms   (vertex words %u of %zu)\n", what, tk[tk.size() / 2], t.nVertexWords, nwords);
+    fflush(stdout);
   };
-  timeMode(std::integral_constant<int, 0>(), "k_count alone");
-  timeMode(std::integral_constant<int, 2>(), "no block scan");
-  timeMode(std::integral_constant<int, 4>(), "no corner logic");
-  timeMode(std::integral_constant<int, 6>(), "faces + wave scans + prefix stores only");
-  // count again without anything in between (bits as the previous count left the caches)
-  {
-    std::vector<float> tk;
-    for (int i = 0; i < reps; i++) {
-      CK(hipMemsetAsync(w.totals, 0, sizeof(Totals), 0));
-      CK(hipEventRecord(a, 0));
-      CK(launch_count(w, g, nwords, 1, 0));
-      CK(hipEventRecord(b, 0));
-      CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b));
-      tk.push_back(ms);
-    }
-    std::sort(tk.begin(), tk.end());
-    printf("count back to back: %.4f ms\n", tk[tk.size() / 2]);
-  }
+#define KC(MODE, TILED, NT, VQ) hipLaunchKernelGGL((k_count<MODE, TILED, NT>), dim3(blocks), dim3(NT), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
+                                                    w.prefix, w.segPre, w.blockTot, VQ, w.totals)
+  printf("n %d wavelength %.0f\n", n, wl);
+  timeIt([&] { KC(0, false, 256, w.vqueue); }, "untiled: everything");
+  timeIt([&] { KC(0, false, 256, (u32 *)nullptr); }, "untiled: no vertex-word queue");
+  timeIt([&] { KC(2, false, 256, w.vqueue); }, "untiled: no block-level scans / queue");
+  timeIt([&] { KC(4, false, 256, w.vqueue); }, "untiled: no corner logic");
+  timeIt([&] { KC(6, false, 256, w.vqueue); }, "untiled: faces + wave scans + prefix stores only");
+  timeIt([&] { KC(0, true, 512, w.vqueue); }, "tiled 512: everything");
+  timeIt([&] { KC(4, true, 512, w.vqueue); }, "tiled 512: no corner logic");
+  timeIt([&] { KC(6, true, 512, w.vqueue); }, "tiled 512: tile + faces + wave scans + prefix stores only");
+  timeIt([&] { KC(0, true, 256, w.vqueue); }, "tiled 256: everything");
+  timeIt([&] { KC(0, true, 1024, w.vqueue); }, "tiled 1024: everything");
   return 0;
 }
