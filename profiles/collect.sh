@@ -12,11 +12,11 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 "$@" > "$OUT/bench.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > "$OUT/bench.json" 2> "$OUT/stats.err"
 echo "stats pass done"
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 "$@" > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/fetch.err"
 echo "FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 "$@" > /dev/null 2> "$OUT/write.err"
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/write.err"
 echo "WRITE_SIZE pass done"
 python3 "$R/profiles/summarize.py" "$OUT" "$R/gpurun_out/$TAG"
 # the raw traces are tens of MiB per pass (gpurun brings back 64 MiB at most): the summaries are what is kept
