@@ -740,57 +740,34 @@ __global__ __launch_bounds__(NT, (TILED ? 4 : 5)) void k_count(const u64 *__rest
     }
     return word_pos(bits, g, y, z, k);
   };
-  // Phase 1 in batches of BATCH words per lane: the centre words of a batch are loaded together, then -- unless the
-  // whole wave sees empty words only (outside regions are whole runs of such words) -- the six neighbour rows of all of
-  // them, unconditionally and back to back: two memory round trips per batch instead of two per word (a block's
-  // latency is what a sparse volume's count costs: 512^3 has four blocks per CU).
-  constexpr int BATCH = 4;
-  for (int i0 = tid; i0 < COUNT_WB; i0 += NT * BATCH) {
-    WordPos wp[BATCH];
-    u64 ctr[BATCH];
-    bool in[BATCH];
-#pragma unroll
-    for (int b = 0; b < BATCH; b++) {
-      const int i = i0 + b * NT;
-      const size_t gi = w0 + i;
-      in[b] = i < COUNT_WB && gi < nwords;
+  for (int i = tid; i < COUNT_WB; i += NT) {
+    const size_t gi = w0 + i;
+    u32 packed = 0;
+    if (gi < nwords) {
       int k, y, z;
-      word_coords(g, in[b] ? gi : w0, k, y, z);          // (a lane past the end reads the block's first word: valid, unused)
-      wp[b] = at(k, y, z);
-      ctr[b] = wp[b].q[0];
-    }
-    u64 anyCtr = 0;
-#pragma unroll
-    for (int b = 0; b < BATCH; b++) anyCtr |= in[b] ? ctr[b] : 0ull;
-    u32 packed[BATCH];
-    if (__ballot(anyCtr != 0ull)) {
-      u64 F[BATCH][6];
-#pragma unroll
-      for (int b = 0; b < BATCH; b++) faces_at(wp[b], g, F[b]);
-#pragma unroll
-      for (int b = 0; b < BATCH; b++) {
+      word_coords(g, gi, k, y, z);
+      const WordPos wp = at(k, y, z);
+      // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
+      // whole runs of such words, so whole waves take the short way)
+      if (wp.q[0] != 0) {
+        u64 F[6];
+        faces_at(wp, g, F);
         int nQ = 0;
 #pragma unroll
-        for (int f = 0; f < 6; f++) nQ += popc64(F[b][f]);
-        packed[b] = in[b] ? (u32)nQ << 16 : 0u;          // (a word without inside voxels has no faces: F is 0 & ...)
+        for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
+        packed = (u32)nQ << 16;
       }
-    } else {
-#pragma unroll
-      for (int b = 0; b < BATCH; b++) packed[b] = 0u;
     }
-#pragma unroll
-    for (int b = 0; b < BATCH; b++) {
-      const int i = i0 + b * NT;
-      if (i < COUNT_WB) cnt[i] = packed[b];
-      // the surface words of the wave take consecutive places in the queue: ONE LDS atomic per wave (an atomic per
-      // word, all on one address, is served one lane after the other)
-      const u64 m = __ballot(packed[b] != 0u);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&nQueued, (int)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (packed[b]) queue[base + (int)__popcll(m & lowmask(lane))] = (unsigned short)i;
-      }
+    cnt[i] = packed;
+    // the surface words of the wave take consecutive places in the queue: ONE LDS atomic per wave (an atomic per word,
+    // all on one address, is served one lane after the other: on a surface that touches most words that was a
+    // measurable part of this kernel)
+    const u64 m = __ballot(packed != 0u);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nQueued, (int)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (packed) queue[base + (int)__popcll(m & lowmask(lane))] = (unsigned short)i;
     }
   }
   __syncthreads();
