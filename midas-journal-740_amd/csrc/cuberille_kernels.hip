@@ -756,19 +756,12 @@ __global__ __launch_bounds__(NT, (TILED ? 4 : 5)) void k_count(const u64 *__rest
 #pragma unroll
         for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
         packed = (u32)nQ << 16;
+        // (one LDS atomic per word; one per wave -- ballot, popcount, broadcast -- was measured: no faster, 7 more
+        //  registers spilled)
+        if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
       }
     }
     cnt[i] = packed;
-    // the surface words of the wave take consecutive places in the queue: ONE LDS atomic per wave (an atomic per word,
-    // all on one address, is served one lane after the other: on a surface that touches most words that was a
-    // measurable part of this kernel)
-    const u64 m = __ballot(packed != 0u);
-    if (m) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&nQueued, (int)__popcll(m));
-      base = __shfl(base, 0, 64);
-      if (packed) queue[base + (int)__popcll(m & lowmask(lane))] = (unsigned short)i;
-    }
   }
   __syncthreads();
   const int nq = (MODE & 4) ? 0 : nQueued;
