@@ -408,6 +408,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
     g.oz1 = (int)(slab->own_z1 - slab->z_begin);
   }
   g.cz0 = g.oz0 > 0 ? g.oz0 - 1 : 0;
+  g.cmapLinear = c->tune.cmap_linear;
   const size_t nrowsAll = (size_t)g.ny * g.nzb;
   const size_t nwordsAll = nrowsAll * g.W;
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
@@ -674,7 +675,9 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   // (more than 2^32 vertices, or no memory) the cell kernel recomputes ids instead
   w.cmap = nullptr;
   if (nV < 0xffffffffULL && !c->tune.no_cmap) {
-    const size_t mapBytes = (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 1) * sizeof(u32);
+    // (4 x 2 x 2 bricks over the lattice corners 0..nx, 0..ny, 0..nzb + 1: the last plane also takes the handed-over one)
+    const size_t mapBytes = c->g.cmapLinear ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 2) * sizeof(u32)
+                                            : (((size_t)c->g.nx + 4) >> 2) * (((size_t)c->g.ny + 2) >> 1) * (((size_t)c->g.nzb + 3) >> 1) * 16 * sizeof(u32);
     if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
     else (void)hipGetLastError();
   }
@@ -1236,7 +1239,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(count_variant) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing)
+  OPT(points_variant) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing)
 #undef OPT
   return false;
 }

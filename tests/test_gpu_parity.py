@@ -737,6 +737,20 @@ try:
     torch.cuda.synchronize()
     res2 = sh.extract(vol, prm)                                                   # the library still works after RCCL ran
     assert (res2.n_points, res2.n_cells) == (res.n_points, res.n_cells) and res.n_points > 1000
+    want = ex.download()
+    # the one-wait step exactly as N ranks run it, with RCCL's all-gather of the rows in device memory (a world of one:
+    # the collective, the two events that order it against the library's stream, the offset summed on the device) --
+    # sized by a host read on a fresh context, then blind
+    ex2 = pkg.Extractor(0)
+    sh2 = ShardedExtractor(ex2, (n, n, n), np.float32, 0, 1, params=prm, thin_halo=False)
+    for _ in range(3):
+        r3 = sh2._extract_step(vol, prm, False)
+        got = ex2.download()
+        assert (r3.n_points, r3.n_cells) == (res.n_points, res.n_cells)
+        assert np.array_equal(got.cells, want.cells) and np.array_equal(got.points.view(np.uint32), want.points.view(np.uint32))
+        assert sh2.stats["collectives"] == 1 and sh2.stats["host_syncs"] == 1, sh2.stats
+        sh2.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+    ex2.close()
     print("RCCL_SMOKE_OK", int(res.n_points), int(res.n_cells))
 finally:
     dist.destroy_process_group()
@@ -745,8 +759,9 @@ finally:
 
 def test_rccl_and_library_share_one_process(tmp_path):
     """One rank, backend nccl (= RCCL): process-group init, all-gather of the counts on device tensors, all-reduce
-    and barrier next to libcuberille_hip.so in the same process (both must bind the HIP runtime torch ships).  The
-    N>1 exchange itself needs more than one GPU; the gloo rehearsals above cover its logic."""
+    and barrier next to libcuberille_hip.so in the same process (both must bind the HIP runtime torch ships); and the
+    one-wait step (cuberille_step_begin -> RCCL all_gather_into_tensor of the rows in device memory -> cuberille_step_end)
+    with that world of one.  The N>1 exchange itself needs more than one GPU; the gloo rehearsals above cover its logic."""
     import socket
     import sys
     s = socket.socket()
@@ -1871,3 +1886,42 @@ def test_recursive_gaussian_gradient_matches_oracle(pkg, oracle, extractor, volu
     with pytest.raises(pkg._abi.CuberilleError) as e:
         extractor.extract_host(vol, pkg.make_params(140, gradient=2))
     assert e.value.code == pkg._abi.ERR_ARGUMENT
+
+
+def test_slice_counts_add_up(pkg, oracle, extractor, volumes):
+    """cuberille_slice_counts: vertices created and quads emitted per owned slice of the last count -- they add up to the
+    totals, equal what the oracle's mesh says slice by slice (a vertex belongs to the slice of the voxel that created it:
+    ids are handed out in raster order, so the per-slice counts are the gaps between the first ids of the slices), on the
+    whole volume and on a slab."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=0, project=0)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    res = extractor.extract_host(vol, pkg.make_params(85, **kw))
+    pts, quads = extractor.slice_counts(nz)
+    assert int(pts.sum()) == int(res.n_points) == len(ref.points) and int(quads.sum()) == int(res.n_cells) == len(ref.cells)
+    # quads per slice from the oracle's cells: a quad's slice is its voxel's z = floor of the smallest corner z + 1/2 ... its
+    # unprojected corners sit at lattice z - 1/2, and the cell order is voxel raster order: count them by the closed form
+    ins = vol.voxels >= 85
+    want_q = np.zeros(nz, dtype=np.int64)
+    for ax in range(3):
+        a = np.moveaxis(ins, ax, 0)
+        up = np.moveaxis(a[:-1] & ~a[1:], 0, ax)            # face towards +axis of the lower voxel
+        dn = np.moveaxis(a[1:] & ~a[:-1], 0, ax)            # face towards -axis of the upper voxel
+        if ax == 0:
+            want_q[:-1] += up.reshape(nz - 1, -1).sum(1)
+            want_q[1:] += dn.reshape(nz - 1, -1).sum(1)
+        else:
+            want_q += up.reshape(nz, -1).sum(1) + dn.reshape(nz, -1).sum(1)
+    assert np.array_equal(quads.astype(np.int64), want_q)
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    a, b = 11, 29
+    lo, hi = a - 3, b + 3
+    extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, hi - lo)), pkg.make_params(85, **kw), pkg._abi.Slab(nz, lo, a, b, 0, 0))
+    p2, q2 = extractor.slice_counts(b - a)
+    assert np.array_equal(q2, quads[a:b]) and np.array_equal(p2, pts[a:b])
+    extractor.emit(0)
+    with pytest.raises(pkg._abi.CuberilleError):
+        extractor.slice_counts(b - a + 1)
