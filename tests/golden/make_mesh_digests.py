@@ -54,6 +54,21 @@ def main():
     with open(os.path.join(HERE, "mesh_digests.json"), "w") as f:
         json.dump(rows, f, indent=1)
     print(len(rows), "rows")
+    # The reference's compiled-out variants (h:21-23): the two other projection branches and the recursive-Gaussian
+    # gradient, triangles + projection at the CLI defaults.  ORACLE output of RESTATED code no reference fixture covers
+    # (the recursive-Gaussian filter is ITK's, restated from its published algorithm: parity unpinned): frozen so that the
+    # restatements cannot drift, and so that the HIP path can be held to them where only the fixtures travel.
+    rows = []
+    for name in sorted(iso_of):
+        vol = pkg.read_mha(os.path.join(HERE, "data", name))
+        for variant, gradient in ((1, 0), (2, 0), (0, 1)):
+            kw = dict(triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=50, variant=variant,
+                      gradient=gradient)
+            m = oracle.run(vol.voxels, iso_of[name], spacing=vol.spacing, origin=vol.origin, direction=vol.direction, **kw)
+            rows.append(dict(input=name, iso=iso_of[name], **kw, **digest(m)))
+    with open(os.path.join(HERE, "variant_digests.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print(len(rows), "variant rows")
 
 
 if __name__ == "__main__":

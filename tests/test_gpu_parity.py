@@ -693,6 +693,21 @@ def test_hip_path_reproduces_committed_mesh_digests(pkg, extractor, volumes):
         assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
 
 
+def test_hip_path_reproduces_committed_variant_digests(pkg, extractor, volumes):
+    """tests/golden/variant_digests.json (33 rows: 11 Data volumes x {advanced, line-search projection, recursive-Gaussian
+    gradient}; frozen oracle output of restated code): the HIP path gives the same bytes without the oracle in the loop."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "variant_digests.json")))
+    for r in rows:
+        mesh = run_gpu(pkg, extractor, volumes(r["input"]), r["iso"], triangles=r["triangles"], project=r["project"],
+                       threshold=r["threshold"], step=r["step"], relax=r["relax"], max_steps=r["max_steps"],
+                       variant=r["variant"], gradient=r["gradient"])
+        assert (mesh.GetNumberOfPoints(), mesh.GetNumberOfCells()) == (r["points"], r["cells"]), r["input"]
+        assert hashlib.sha256(_point_bytes(mesh.points)).hexdigest() == r["points_sha256"], r
+        assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
+
+
 def test_cxx_flat_writer_route_matches_mesh_route(tmp_path):
     """midas-journal-740_amd/itk/tests/end_to_end.cxx: itk::Mesh fill + itk::VTKPolyDataWriter vs
     WriteLastMeshAsVTKPolyData (flat device buffers -> file) write the same bytes, quads and triangles."""

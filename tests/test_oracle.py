@@ -162,6 +162,23 @@ def test_oracle_reproduces_committed_mesh_digests(pkg, oracle, volumes):
         assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
 
 
+def test_oracle_reproduces_committed_variant_digests(pkg, oracle, volumes):
+    """tests/golden/variant_digests.json: the oracle's restatements of the reference's compiled-out variants (the two
+    other projection branches, the recursive-Gaussian gradient) frozen on every Data volume."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "variant_digests.json")))
+    assert len(rows) == 33
+    for r in rows:
+        vol = volumes(r["input"])
+        m = oracle.run(vol.voxels, r["iso"], triangles=r["triangles"], project=r["project"], threshold=r["threshold"],
+                       step=r["step"], relax=r["relax"], max_steps=r["max_steps"], variant=r["variant"],
+                       gradient=r["gradient"], spacing=vol.spacing, origin=vol.origin, direction=vol.direction)
+        assert (m.points.shape[0], m.cells.shape[0]) == (r["points"], r["cells"]), r["input"]
+        assert hashlib.sha256(_point_bytes(m.points)).hexdigest() == r["points_sha256"], (r["input"], r["variant"], r["gradient"])
+        assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
+
+
 def test_oracle_reproduces_bench_field_digests(pkg, oracle):
     """tests/golden/bench_field_digests.json (made by make_bench_field_digests.py): the oracle on the bench's own
     bit-portable fields is frozen too, so the checker of the GPU parity tests on those fields cannot drift."""
