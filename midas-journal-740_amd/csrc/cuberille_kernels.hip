@@ -934,10 +934,6 @@ __device__ __forceinline__ size_t corner_map_index(const Grid &g, int cx, int cy
   const size_t brick = ((size_t)(cz >> 1) * by + (size_t)(cy >> 2)) * bx + (size_t)(cx >> 2);
   return brick * 32 + (size_t)((((cy >> 1) & 1) << 4) | ((cz & 1) << 3) | ((cy & 1) << 2) | (cx & 3));
 }
-  const size_t by = (size_t)(g.ny + 4) >> 2;
-  const size_t brick = ((size_t)(cz >> 1) * by + (size_t)(cy >> 2)) * bx + (size_t)(cx >> 2);
-  return brick * 32 + (size_t)((((cy >> 1) & 1) << 4) | ((cz & 1) << 3) | ((cy & 1) << 2) | (cx & 3));
-}
 
 __device__ __forceinline__ size_t word_index(const Grid &g, int y, int z, int k) {
   return ((size_t)(z - g.cz0) * g.ny + y) * g.W + k;
