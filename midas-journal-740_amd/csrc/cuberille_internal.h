@@ -97,11 +97,12 @@ struct Tuning {
   int no_cmap = 0, no_heads = 0, no_vqueue = 0, no_stream_classify = 0;   // drop a scratch table / the flat-stream path
   int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
+  int points_no_split = 0;    // 1: the point pass runs one lane per vertex word however short the queue
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
                               // the previous extraction on the context found vertices in a quarter of its words or more
-  int proj_chunk = 128, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
+  int proj_chunk = 0, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
 

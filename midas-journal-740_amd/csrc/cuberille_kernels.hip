@@ -1142,6 +1142,9 @@ __global__ __launch_bounds__(256) void k_emit_points_wave(EmitArgs a, Grid g, Ge
 // slice holds (cannot happen on smooth surfaces) walks and stores directly.
 constexpr int POINTS_CAP = 1024;                 // descriptors per wave
 
+// SPLIT lanes share a vertex word, each walking 64 / SPLIT of its voxels (short queues: the walk of phase 1 is serial per
+// lane -- up to 64 voxels with corners on the flat faces of the reference's small volumes -- and there are wave slots to spare).
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, Geo geo, const u32 *__restrict__ vqueue,
                                                            u32 nVertexWords) {
   __shared__ unsigned short desc[4][POINTS_CAP];
@@ -1154,14 +1157,15 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
     if (!a.tot->go) return;
     nVertexWords = a.tot->nVertexWords;
   }
-  if (t - lane >= nVertexWords) return;          // wave-uniform
-  const bool valid = t < nVertexWords;
+  if ((t - lane) / SPLIT >= nVertexWords) return;   // wave-uniform
+  const bool valid = t / SPLIT < nVertexWords;
+  const u64 mine = SPLIT == 1 ? ~0ull : ((1ull << (64 / SPLIT)) - 1ull) << ((t % SPLIT) * (64 / SPLIT));   // this lane's voxels
   WordInfo w;
   int k = 0, y = 0, z = 0;
   u64 v0 = 0;
   u32 cnt = 0;
   if (valid) {
-    const u32 gi = vqueue[t];
+    const u32 gi = vqueue[t / SPLIT];
     const u32 row = gi / (u32)g.W;
     k = (int)(gi - row * (u32)g.W);
     const u32 zz = row / (u32)g.ny;
@@ -1171,14 +1175,17 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
     classify_word<false>(a.bits, a.occ, g, a.q1, y, z, k, w, unk);
     v0 = seg_base<0>(a, gi) + (a.prefix[gi] & 0xffffu);        // id of this word's first vertex
 #pragma unroll
-    for (int i = 0; i < 8; i++) cnt += (u32)popc64(w.C[i]);
+    for (int i = 0; i < 8; i++) {
+      if (SPLIT > 1) v0 += (u32)popc64(w.C[i] & lowmask((int)(t % SPLIT) * (64 / SPLIT)));   // ... of this lane's first
+      cnt += (u32)popc64(w.C[i] & mine);
+    }
   }
   const u32 incl = wave_inclusive_sum(cnt);
   const u32 off = incl - cnt;
   const u32 total = __shfl(incl, 63, 64);
   const bool dense = total <= (u32)POINTS_CAP;   // wave-uniform
   if (valid) {
-    u64 any = w.C[0] | w.C[1] | w.C[2] | w.C[3] | w.C[4] | w.C[5] | w.C[6] | w.C[7];
+    u64 any = (w.C[0] | w.C[1] | w.C[2] | w.C[3] | w.C[4] | w.C[5] | w.C[6] | w.C[7]) & mine;
     u32 j = off;
     u64 v = v0;
     while (any) {
@@ -2310,9 +2317,12 @@ hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo,
   const size_t nwords = (size_t)(g.oz1 - g.cz0) * g.ny * g.W;
   EmitArgs a = emit_args(w, g, q1, 0);
   a.dyn = dyn;                                   // (only the queue form below is ever launched blindly)
-  if (w.vqueue && nwords < 0xffffffffULL && tn.points_variant == 3)
-    hipLaunchKernelGGL(k_emit_points_dense, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
-  else
+  if (w.vqueue && nwords < 0xffffffffULL && tn.points_variant == 3) {
+    if (nVertexWords <= 32768u && !tn.points_no_split)
+      hipLaunchKernelGGL(k_emit_points_dense<8>, dim3(grid_for((u64)nVertexWords * 8, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
+    else
+      hipLaunchKernelGGL(k_emit_points_dense<1>, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
+  } else
     hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, a, g, geo, nwords, nV);
   return hipGetLastError();
 }
@@ -2410,7 +2420,9 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms
   // for one contiguous chunk of 256 per wave; u8 noise prefers contiguous, 2.23 vs 2.35 ms; earlier runs:
   // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)
-  u64 chunk = tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk;
+  // (a launch that leaves wave slots empty -- every volume the reference ships -- deals 64 per wave: one vertex per lane, no
+  //  refill, the kernel ends with its slowest walk instead of with a wave's second helping; nucleon 0.212 -> 0.163 ms wall)
+  u64 chunk = tn.proj_chunk <= 0 ? (nPoints <= 64ull * 4096 ? 64 : 128) : tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk;
   const u64 gridWaves = (u64)tn.proj_waves;
   while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
   u64 nwaves = (nPoints + chunk - 1) / chunk;

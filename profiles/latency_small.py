@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wall time of one whole extraction (count + host round trip + emit) on the reference's own small volumes, voxels
-resident on the device:  python profiles/latency_small.py  -> one line per volume (median of 200 calls)."""
+resident on the device:  python profiles/latency_small.py [name=value ...]  -> one line per volume (median of 200
+calls); name=value: development switches of the context (cuberille_debug_set_option)."""
 import os
 import sys
 import time
@@ -16,6 +17,9 @@ def main():
     import torch
     pkg = graft.load_package()
     ex = pkg.Extractor(0)
+    for kv in sys.argv[1:]:
+        name, value = kv.split("=")
+        ex.debug_option(name, int(value))
     data = os.path.join(ROOT, "tests", "golden", "data")
     for name, iso in [("blob0.mha", 200), ("nucleon.mha", 128), ("fuel.mha", 15), ("silicium.mha", 85), ("hydrogenAtom.mha", 15),
                       ("engine.mha", 100)]:
