@@ -695,7 +695,7 @@ constexpr int TILE_PLANE = COUNT_WB + 4 * TILE_WMAX;      // words per staged sl
 // (untiled, 5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill
 //  too much)
 template <int MODE, bool TILED, int NT>   // MODE 0 in the library; 2: no block scan, 4: no corner logic (microbench)
-__global__ __launch_bounds__(NT, (TILED ? 4 : 5)) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
+__global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
                                                size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
                                                u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
                                                Totals *__restrict__ tot) {
@@ -2275,6 +2275,11 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
   if (tiled && g.W <= TILE_WMAX)
     hipLaunchKernelGGL((k_count<0, true, 512>), dim3(blocks), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                       w.blockTot, vq, w.totals);
+  else if (blocks <= 64)
+    // (a handful of blocks -- every volume the reference ships: the kernel's time is a block's latency, two trips through its
+    //  loops instead of eight)
+    hipLaunchKernelGGL((k_count<0, false, 1024>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals);
   else
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
