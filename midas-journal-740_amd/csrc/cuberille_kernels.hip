@@ -429,8 +429,8 @@ __device__ __forceinline__ WordPos word_pos(const u64 *__restrict__ bits, const 
 }
 
 // The same word inside a staged copy of the bit rows (the count kernel's LDS tile): `q` points at the word's copy, rows
-// are W words apart as in memory, the slices z-1 / z+1 sit `plane` words before / after.
-__device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long plane, const Grid &g, int y, int z, int k) {
+// are W words apart as in memory, the copies of the slices z-1 / z+1 sit `below` / `above` words from it.
+__device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long below, long long above, const Grid &g, int y, int z, int k) {
   WordPos w;
   w.q = q;
   w.k = k; w.y = y; w.z = z;
@@ -438,7 +438,7 @@ __device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long plane, 
   w.kp = k < g.W - 1 ? 1 : 0;
   const long long rs = g.W;
   w.yo[0] = y > 0 ? -rs : 0;          w.yo[1] = 0;  w.yo[2] = y < g.ny - 1 ? rs : 0;
-  w.zo[0] = z > 0 ? -plane : 0;       w.zo[1] = 0;  w.zo[2] = z < g.nzb - 1 ? plane : 0;
+  w.zo[0] = z > 0 ? below : 0;        w.zo[1] = 0;  w.zo[2] = z < g.nzb - 1 ? above : 0;
   return w;
 }
 
@@ -691,6 +691,7 @@ __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independe
 // Rows wider than TILE_WMAX words (nx > 6144) take the untiled form.
 constexpr int TILE_WMAX = 96;
 constexpr int TILE_PLANE = COUNT_WB + 4 * TILE_WMAX;      // words per staged slice: the block's rows (two of them partly) + 2
+constexpr int COUNT_ZRUN = 8;                             // blocks a workgroup of the column form takes, one above the other
 
 // (untiled, 5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill
 //  too much)
@@ -698,7 +699,7 @@ template <int MODE, bool TILED, int NT>   // MODE 0 in the library; 2: no block 
 __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
                                                size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
                                                u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
-                                               Totals *__restrict__ tot) {
+                                               Totals *__restrict__ tot, int zrun) {
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
   __shared__ unsigned short queue[COUNT_WB];
   __shared__ u64 segTot[COUNT_WB / 64];
@@ -709,10 +710,19 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
   __shared__ u64 tile[TILED ? 3 * TILE_PLANE : 1];
   constexpr int NWAVES = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const size_t w0 = (size_t)blockIdx.x * COUNT_WB;
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
+  // zrun > 0 (TILED, slices that are whole count blocks): the workgroup takes the SAME rows of zrun consecutive slices, one
+  // count block after the other, and keeps the staged planes: per block one new plane is copied instead of three
+  if (!TILED) zrun = 0;                          // (the untiled forms keep their one block: the loop folds away)
+  const u32 bps = zrun ? (u32)(((size_t)g.ny * g.W) >> COUNT_LG) : 1u;        // count blocks per slice
+  const u32 colBlock = zrun ? blockIdx.x % bps : 0u, colRun = zrun ? blockIdx.x / bps : 0u;
+  for (int it = 0; it < (zrun ? zrun : 1); it++) {
+  const u32 blk = zrun ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x;
+  const size_t w0 = (size_t)blk * COUNT_WB;
+  if (w0 >= nwords) break;                       // (the same for every thread)
   if (tid == 0) { nQueued = 0; g0InSeg = 0; }
   long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
+  int slot = 1;                                  // ... and which third of the tile holds the block's own slice
   if (TILED) {
     int k0, y0, z0, k1, y1, z1;
     word_coords(g, w0, k0, y0, z0);
@@ -722,21 +732,35 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
     const long long rowLast = (long long)z1 * g.ny + y1;
     const int len = (int)(rowLast - rowFirst + 3) * g.W;    // the block's rows, one before, one after
     const long long nbuf = (long long)g.nzb * g.ny * g.W;
+    if (it == 0) {
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-      const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
+      for (int p = 0; p < 3; p++) {
+        const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
+        for (int j = tid; j < len; j += NT) {
+          const long long gidx = gstart + j;
+          tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+        }
+      }
+    } else {
+      // the planes roll: the slice above the previous block is this block's own, the new slice above takes the place of
+      // the one that was below (every thread is past its last read of it: the barrier behind phase 2).  (Loading it a
+      // phase early into registers, behind that barrier, was measured: 13 spilled registers, 2.09 vs 1.86 ms.)
+      slot = (it + 1) % 3;
+      const int fresh = (it + 2) % 3;
+      const long long gstart = (rowFirst - 1 + (long long)g.ny) * g.W;
       for (int j = tid; j < len; j += NT) {
         const long long gidx = gstart + j;
-        tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+        tile[fresh * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;
       }
     }
   }
   __syncthreads();
+  const long long planeBelow = (long long)((slot + 2) % 3 - slot) * TILE_PLANE, planeAbove = (long long)((slot + 1) % 3 - slot) * TILE_PLANE;
   // where word (k, y, z) of this block is read from
   auto at = [&](int k, int y, int z) -> WordPos {
     if (TILED) {
       const long long t = (long long)z * g.ny + y - rowFirst + 1;
-      return word_pos_tile(&tile[TILE_PLANE + t * g.W + k], TILE_PLANE, g, y, z, k);
+      return word_pos_tile(&tile[slot * TILE_PLANE + t * g.W + k], planeBelow, planeAbove, g, y, z, k);
     }
     return word_pos(bits, g, y, z, k);
   };
@@ -805,7 +829,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       if (lane == 0 && total) vbase = atomicAdd(&tot->nVertexWords, total);
     }
   }
-  if (MODE & 2) return;
+  if (MODE & 2) continue;
   if (wv == 0) {
     // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
     const u64 t = lane < COUNT_WB / 64 ? segTot[lane] : 0ull;
@@ -813,11 +837,11 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
     const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
     const size_t seg = (w0 >> 6) + lane;
     if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
-    if (g0 > 0 && (g0 >> COUNT_LG) == blockIdx.x && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
+    if (g0 > 0 && (g0 >> COUNT_LG) == blk && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
       const u32 in = g0InSeg;
       tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
     }
-    if (lane == COUNT_WB / 64 - 1) blockTot[blockIdx.x] = incl;
+    if (lane == COUNT_WB / 64 - 1) blockTot[blk] = incl;
   }
   if (vqueue) {
     __syncthreads();
@@ -827,6 +851,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
         vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
     }
   }
+  }   // the workgroup's next block
 }
 
 // Exclusive scan of the count blocks' totals (V | Q<<32 each) -> blockBase[2b], [2b+1] and the grand totals.  One
@@ -2273,17 +2298,22 @@ hipError_t launch_occupancy(int pixel_type, const Workspace &w, const Grid &g, c
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
-  if (tiled && g.W <= TILE_WMAX)
-    hipLaunchKernelGGL((k_count<0, true, 512>), dim3(blocks), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals);
-  else if (blocks <= 64)
+  const size_t sliceWords = (size_t)g.ny * g.W;
+  if (tiled && g.W <= TILE_WMAX) {
+    // (slices that are whole count blocks: a workgroup walks up a column of COUNT_ZRUN blocks and re-uses two of its three planes)
+    const int want = tiled == 1 ? COUNT_ZRUN : tiled >= 4 ? tiled : 0;      // (tiled 2: one block per workgroup; >= 4: that run)
+    const int zrun = want && sliceWords % COUNT_WB == 0 && g.oz1 - g.cz0 >= 2 * want ? want : 0;
+    const unsigned grid = zrun ? (unsigned)(sliceWords / COUNT_WB) * (unsigned)((g.oz1 - g.cz0 + zrun - 1) / zrun) : blocks;
+    hipLaunchKernelGGL((k_count<0, true, 512>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                       w.blockTot, vq, w.totals, zrun);
+  } else if (blocks <= 64)
     // (a handful of blocks -- every volume the reference ships: the kernel's time is a block's latency, two trips through its
     //  loops instead of eight)
     hipLaunchKernelGGL((k_count<0, false, 1024>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals);
+                       w.blockTot, vq, w.totals, 0);
   else
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals);
+                       w.blockTot, vq, w.totals, 0);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
   hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate);
   return hipGetLastError();

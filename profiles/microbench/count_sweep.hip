@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
     fflush(stdout);
   };
 #define KC(MODE, TILED, NT, VQ) hipLaunchKernelGGL((k_count<MODE, TILED, NT>), dim3(blocks), dim3(NT), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
-                                                    w.prefix, w.segPre, w.blockTot, VQ, w.totals)
+                                                    w.prefix, w.segPre, w.blockTot, VQ, w.totals, 0)
   printf("n %d wavelength %.0f\n", n, wl);
   timeIt([&] { KC(0, false, 256, w.vqueue); }, "untiled: everything");
   timeIt([&] { KC(0, false, 256, (u32 *)nullptr); }, "untiled: no vertex-word queue");

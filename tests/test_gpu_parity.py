@@ -396,18 +396,21 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
 
 
 @pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"),
-                                     ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",)])
+                                     ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",),
+                                     ("points_no_split", "proj_chunk=128"), ("cmap_linear",)])
 def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, options):
     """When the dense corner map (4 B per lattice corner), the head tables or the vertex-word queue cannot be
     allocated the kernels recompute ids / search the prefix arrays instead; the sweep also runs without its staged
-    spans; same mesh every way.  The switches are per-context
+    spans; the launch shapes of large volumes (one lane per vertex word, 128 vertices per wave of the walk, the corner map
+    in raster order) on small ones; same mesh every way.  The switches are per-context
     options of the C ABI (cuberille_debug_set_option), not environment variables."""
     rng = np.random.default_rng(11)
     vox = rng.integers(0, 255, size=(9, 10, 130), dtype=np.uint8)
     vox[4] = 0                                    # an empty slice: exercises the aliasing redirect too
     try:
         for o in options:
-            extractor.debug_option(o, 1)
+            name, _, value = o.partition("=")
+            extractor.debug_option(name, int(value or 1))
         for vol, iso in [(volumes("nucleon.mha"), 128), (volumes("silicium.mha"), 85), (pkg.Volume(vox), 128)]:
             for tri in (0, 1):
                 kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
@@ -417,6 +420,39 @@ def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, 
         extractor.debug_option("defaults", 0)
     with pytest.raises(pkg._abi.CuberilleError):
         extractor.debug_option("no_such_switch", 1)
+
+
+@pytest.mark.parametrize("shape", [(128, 1024, 20), (256, 96, 24), (192, 64, 40)])
+def test_count_forms_agree_with_oracle(pkg, oracle, extractor, shape):
+    """The three forms of the count kernel -- untiled, LDS-tiled one block per workgroup, LDS-tiled with a workgroup walking
+    up a column of blocks (slices that are whole count blocks: the first shape; the others have blocks that straddle rows
+    and slices) -- on the same fields: whole volumes against the oracle, and a slab with a ghost slice against the whole."""
+    import torch
+    nx, ny, nz = shape
+    vox = pkg.volumes.gradient_noise(nx, ny, nz, base_period=32)
+    vox[nz // 2] = 0                              # an empty slice: quirk Q1 inside a column of blocks
+    vol = pkg.Volume(vox)
+    kw = dict(triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+    ref = oracle.run(vox, 128, **kw)
+    prm = pkg.make_params(128, **kw)
+    dev = torch.from_numpy(vox).cuda()
+    a, b = 3, nz - 2
+    try:
+        for form in (0, 1, 2):
+            extractor.debug_option("count_variant", form)
+            assert_same_mesh(run_gpu(pkg, extractor, vol, 128, **kw), ref)
+            # a slab: ghost slice below its owned range, halo above
+            slab = pkg._abi.Slab(nz, 0, a, b, 0, 0)
+            n_p, n_c = extractor.count(dev.data_ptr(), pkg.make_desc(vox.dtype, (nx, ny, nz)), prm, slab)
+            extractor.emit(0)
+            m = extractor.download()
+            if form == 0:
+                first = m
+            else:
+                assert np.array_equal(m.cells, first.cells)
+                assert np.array_equal(m.points.view(np.uint32), first.points.view(np.uint32))
+    finally:
+        extractor.debug_option("defaults", 0)
 
 
 def _closed_form_counts_torch(ins):
