@@ -428,7 +428,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   // the totals and the per-slice occupancy share one allocation: one memset zeroes both
   static_assert(sizeof(Totals) % 16 == 0, "the occupancy words follow the totals");
   HIP_TRY(c, c->occ.reserve(sizeof(Totals) + (size_t)g.nzb * sizeof(u32)));
-  HIP_TRY(c, c->prefix.reserve(nwords * sizeof(u32)));
+  HIP_TRY(c, c->prefix.reserve((nwords + 4) * sizeof(u32)));   // (+ the tail of a 16-byte read at the last words: locate_word_wave)
   HIP_TRY(c, c->segPre.reserve(nseg * sizeof(u64)));
   HIP_TRY(c, c->blockTot.reserve(nblk * sizeof(u64)));
   HIP_TRY(c, c->blockBase.reserve(nblk * 2 * sizeof(u64)));

@@ -1081,38 +1081,54 @@ __global__ __launch_bounds__(256) void k_heads_search(EmitArgs a, size_t nwords,
 }
 
 // Per-wave form of the search: a wave holds 64 consecutive outputs, which come from a short run of words:
-// `head[o/64]` names the word that produces output o & ~63; the 64 lanes load the absolute prefixes of the 64 words
-// from there on and each lane finds its own word with a 6-step shuffle search -- two dependent memory round trips
-// instead of the ~25 of a per-lane search.  Outputs that lie beyond the window (sparse surface) slide the window;
-// after a few slides the lane falls back to locate_word.
+// `head[o/64]` names the word that produces output o & ~63; the 64 lanes load the absolute prefixes of the 256 words
+// from there on -- four consecutive words per lane, ONE 16-byte load of the prefix array plus the segment's base (a group of
+// four aligned words shares its segment) -- and each lane finds its own word with a 6-step shuffle search over the
+// groups and a look at the four words of its group: two dependent memory round trips instead of the ~25 of a per-lane
+// search.  (A window of 64 words, one per lane, slid two or three times on a surface like the Marschner-Lobb sheet,
+// where 64 quads come from ~19 words spread over ~130: every slide one more dependent round trip.)  Outputs that lie
+// beyond the window slide it; after a few slides the lane falls back to locate_word.  The prefix array is readable up
+// to three words past `nwords` (cuberille_api.hip reserves them).
 // All 64 lanes of the wave must call this together (idx = consecutive outputs, `valid` lanes only).
 template <int SHIFT>
 __device__ __forceinline__ size_t locate_word_wave(const EmitArgs &a, const u32 *__restrict__ head, size_t nwords, u64 idx,
                                                    bool valid, u32 &within) {
   const int lane = threadIdx.x & 63;
   const u64 first = __shfl(idx, 0, 64);          // lane 0 is always valid; first is a multiple of 64
-  size_t w0 = head[first >> 6];
+  size_t w0 = (size_t)head[first >> 6] & ~(size_t)3;   // (the words of the head's group before it produce earlier outputs)
   size_t found = 0;
   bool done = !valid;
   for (int slide = 0; slide < 4; slide++) {
-    const size_t w = w0 + lane;
-    const u64 A = (w < nwords) ? seg_base<SHIFT>(a, w) + ((a.prefix[w] >> SHIFT) & 0xffffu) : ~0ull;
-    // first output of word w relative to the wave's first output: the head word starts at most one word's
-    // worth (< 2^16) below it, everything that matters is <= 63, so 32 bits hold it exactly (large values clamp)
-    const long long rel = (long long)(A - first);
-    const int t = (A == ~0ull || rel > (1 << 20)) ? (1 << 20) : (int)rel;
-    int lo = 0, hi = 64;                         // largest j with t[j] <= lane  (A[j] <= idx)
+    const size_t w = w0 + 4 * (size_t)lane;      // this lane's four words
+    int t[4];
+    if (w < nwords) {
+      const uint4 pw = *reinterpret_cast<const uint4 *>(a.prefix + w);
+      const u64 base = seg_base<SHIFT>(a, w);
+      const u32 p4[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        // first output of the word relative to the wave's first output: the head word starts at most one word's worth
+        // (< 2^16) below it, everything that matters is <= 63, so 32 bits hold it exactly (large values clamp)
+        const long long rel = (long long)(base + ((p4[i] >> SHIFT) & 0xffffu) - first);
+        t[i] = (w + i >= nwords || rel > (1 << 20)) ? (1 << 20) : (int)rel;
+      }
+    } else {
+      t[0] = t[1] = t[2] = t[3] = 1 << 20;
+    }
+    int lo = 0, hi = 64;                         // largest group whose first word starts at or before this lane's output
 #pragma unroll
     for (int st = 0; st < 6; st++) {
       const int mid = (lo + hi) >> 1;
-      const int v = __shfl(t, mid, 64);
+      const int v = __shfl(t[0], mid, 64);
       if (v <= lane) lo = mid; else hi = mid;
     }
-    const int tlo = __shfl(t, lo, 64);
+    const int g0 = __shfl(t[0], lo, 64), g1 = __shfl(t[1], lo, 64), g2 = __shfl(t[2], lo, 64), g3 = __shfl(t[3], lo, 64);
+    const int i = g3 <= lane ? 3 : g2 <= lane ? 2 : g1 <= lane ? 1 : 0;
+    const int tw = i == 3 ? g3 : i == 2 ? g2 : i == 1 ? g1 : g0;
     // inside the window unless the last loaded word is still <= idx (its successor is unknown)
-    if (!done && lo < 63) { found = w0 + lo; within = (u32)(lane - tlo); done = true; }
+    if (!done && (lo < 63 || i < 3)) { found = w0 + 4 * (size_t)lo + i; within = (u32)(lane - tw); done = true; }
     if (!__ballot(!done)) return found;
-    w0 += 63;
+    w0 += 252;
   }
   if (!done) found = locate_word<SHIFT>(a, nwords, idx, within);
   return found;

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--workload", default="marschner_lobb")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--quads", action="store_true", help="quadrilateral cells (no split, no point gathers in the cell pass)")
     ap.add_argument("sweeps", nargs="*")
     args = ap.parse_args()
     import torch
@@ -31,7 +32,7 @@ def main():
     torch.cuda.synchronize()
     ex = pkg.Extractor(0)
     desc = pkg.make_desc(dtype, (n, n, n))
-    prm = pkg.make_params(iso, triangles=True, project=True, threshold=thr, step=0.25, relax=0.95, max_steps=50)
+    prm = pkg.make_params(iso, triangles=not args.quads, project=True, threshold=thr, step=0.25, relax=0.95, max_steps=50)
     names, values = [], []
     for sw in args.sweeps:
         k, v = sw.split("=")

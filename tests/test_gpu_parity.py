@@ -380,9 +380,12 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
         if relax == 1.0:
             assert sum(st[0]["escaped"] for st in stats) > 0
     if mode == "step_balanced":
-        # silicium's surface is spread unevenly over its 40 slices: the balanced cuts differ from 10-10-10-10
+        # every rank derives the same cuts from the all-reduced per-slice work (measured times: where they fall is the
+        # box's business -- tests/test_distributed.py pins balanced_bounds itself), and they tile the 40 slices
         bounds = stats[0][-1]["bounds"]
-        assert all(st[-1]["bounds"] == bounds for st in stats) and [b - a for a, b in bounds] != [10, 10, 10, 10]
+        assert all(st[-1]["bounds"] == bounds for st in stats)
+        assert bounds[0][0] == 0 and bounds[-1][1] == 40 and all(b > a for a, b in bounds)
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
     elif mode.startswith("step"):
         assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 2) for st in stats), stats
 
