@@ -77,6 +77,7 @@ struct cuberille_ctx {
   u64 histV = 0, histQ = 0;
   u32 histVW = 0;
   bool histDense = false;                // ... and whether a quarter or more of its words created vertices
+  bool histShortWalks = false;           // ... and whether its walks took fewer than four passes per vertex on average
   int stepMode = 0;                      // 0: no step open; 1: launched blindly (sizes on the device); 2: sized by a host read
   Totals *hostRows = nullptr;            // pinned: the gathered totals of all ranks, read back by cuberille_step_end
   size_t hostRowsCap = 0;
@@ -725,8 +726,13 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
     }
     HIP_TRY(c, launch_recursive_gaussian(c->pixel_type, w, c->g, c->geo, coef, s));
   }
-  if (c->prm.project)
-    HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, c->tune, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
+  if (c->prm.project) {
+    // (walks that end after two or three passes -- a noise field -- leave the kernel bound by its gathers, which a refill
+    //  issues for the few lanes it fills: such fields refill only empty waves.  Scheduling only: results never depend on it.)
+    Tuning tn = c->tune;
+    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : 16;
+    HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, tn, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
+  }
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
   c->pointsEmitted = true;
   return CUBERILLE_OK;
@@ -776,6 +782,7 @@ int finish_result(cuberille_ctx *c, cuberille_result *res) {
   c->haveHistory = true;
   c->histV = c->tot.totV; c->histQ = c->tot.totQ; c->histVW = c->tot.nVertexWords;
   c->histDense = (u64)c->tot.nVertexWords * 4 >= (u64)c->nwords;
+  c->histShortWalks = c->prm.project && c->tot.iters > 0 && c->tot.iters < 4 * c->tot.totV;
   c->stepMode = 0;
   c->haveMesh = true;
   c->counted = false;                        // the workspace now belongs to this mesh
@@ -847,7 +854,9 @@ int cuberille_reproject_escaped(cuberille_ctx *c, const void *dev_voxels, int64_
   deep.zglob0 = z_begin;
   Workspace w = c->w;
   w.vox = dev_voxels;
-  HIP_TRY(c, launch_project(c->pixel_type, w, deep, c->geo, c->prm, n, c->tot.V0, c->tune, 2, 0, c->stream));
+  Tuning tn = c->tune;
+  if (tn.proj_refill <= 0) tn.proj_refill = 16;
+  HIP_TRY(c, launch_project(c->pixel_type, w, deep, c->geo, c->prm, n, c->tot.V0, tn, 2, 0, c->stream));
   // nobody waits any more (the list's length travelled by value): the device-side counter starts over
   HIP_TRY(c, hipMemsetAsync(&c->w.totals->nEscaped, 0, sizeof(u32), c->stream));
   c->tot.nEscaped = 0;

@@ -102,7 +102,7 @@ struct Tuning {
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
                               // the previous extraction on the context found vertices in a quarter of its words or more
-  int proj_chunk = 0, proj_waves = 16384, proj_refill = 16, proj_xcd = 0, proj_literal = 0;
+  int proj_chunk = 0, proj_waves = 16384, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
 

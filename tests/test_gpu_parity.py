@@ -400,12 +400,12 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
 
 @pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"),
                                      ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",),
-                                     ("points_no_split", "proj_chunk=128"), ("cmap_linear",)])
+                                     ("points_no_split", "proj_chunk=128"), ("cmap_linear",), ("proj_refill=64",), ("proj_refill=3", "proj_chunk=256")])
 def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, options):
     """When the dense corner map (4 B per lattice corner), the head tables or the vertex-word queue cannot be
     allocated the kernels recompute ids / search the prefix arrays instead; the sweep also runs without its staged
     spans; the launch shapes of large volumes (one lane per vertex word, 128 vertices per wave of the walk, the corner map
-    in raster order) on small ones; same mesh every way.  The switches are per-context
+    in raster order) on small ones; waves of the walk that refill only when empty, or at three idle lanes; same mesh every way.  The switches are per-context
     options of the C ABI (cuberille_debug_set_option), not environment variables."""
     rng = np.random.default_rng(11)
     vox = rng.integers(0, 255, size=(9, 10, 130), dtype=np.uint8)
