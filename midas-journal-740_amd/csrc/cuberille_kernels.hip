@@ -717,140 +717,140 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
   const u32 bps = zrun ? (u32)(((size_t)g.ny * g.W) >> COUNT_LG) : 1u;        // count blocks per slice
   const u32 colBlock = zrun ? blockIdx.x % bps : 0u, colRun = zrun ? blockIdx.x / bps : 0u;
   for (int it = 0; it < (zrun ? zrun : 1); it++) {
-  const u32 blk = zrun ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x;
-  const size_t w0 = (size_t)blk * COUNT_WB;
-  if (w0 >= nwords) break;                       // (the same for every thread)
-  if (tid == 0) { nQueued = 0; g0InSeg = 0; }
-  long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
-  int slot = 1;                                  // ... and which third of the tile holds the block's own slice
-  if (TILED) {
-    int k0, y0, z0, k1, y1, z1;
-    word_coords(g, w0, k0, y0, z0);
-    const size_t wl = w0 + COUNT_WB - 1 < nwords ? w0 + COUNT_WB - 1 : nwords - 1;
-    word_coords(g, wl, k1, y1, z1);
-    rowFirst = (long long)z0 * g.ny + y0;
-    const long long rowLast = (long long)z1 * g.ny + y1;
-    const int len = (int)(rowLast - rowFirst + 3) * g.W;    // the block's rows, one before, one after
-    const long long nbuf = (long long)g.nzb * g.ny * g.W;
-    if (it == 0) {
+    const u32 blk = zrun ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x;
+    const size_t w0 = (size_t)blk * COUNT_WB;
+    if (w0 >= nwords) break;                       // (the same for every thread)
+    if (tid == 0) { nQueued = 0; g0InSeg = 0; }
+    long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
+    int slot = 1;                                  // ... and which third of the tile holds the block's own slice
+    if (TILED) {
+      int k0, y0, z0, k1, y1, z1;
+      word_coords(g, w0, k0, y0, z0);
+      const size_t wl = w0 + COUNT_WB - 1 < nwords ? w0 + COUNT_WB - 1 : nwords - 1;
+      word_coords(g, wl, k1, y1, z1);
+      rowFirst = (long long)z0 * g.ny + y0;
+      const long long rowLast = (long long)z1 * g.ny + y1;
+      const int len = (int)(rowLast - rowFirst + 3) * g.W;    // the block's rows, one before, one after
+      const long long nbuf = (long long)g.nzb * g.ny * g.W;
+      if (it == 0) {
 #pragma unroll
-      for (int p = 0; p < 3; p++) {
-        const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
+        for (int p = 0; p < 3; p++) {
+          const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
+          for (int j = tid; j < len; j += NT) {
+            const long long gidx = gstart + j;
+            tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+          }
+        }
+      } else {
+        // the planes roll: the slice above the previous block is this block's own, the new slice above takes the place of
+        // the one that was below (every thread is past its last read of it: the barrier behind phase 2).  (Loading it a
+        // phase early into registers, behind that barrier, was measured: 13 spilled registers, 2.09 vs 1.86 ms.)
+        slot = (it + 1) % 3;
+        const int fresh = (it + 2) % 3;
+        const long long gstart = (rowFirst - 1 + (long long)g.ny) * g.W;
         for (int j = tid; j < len; j += NT) {
           const long long gidx = gstart + j;
-          tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+          tile[fresh * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;
         }
       }
-    } else {
-      // the planes roll: the slice above the previous block is this block's own, the new slice above takes the place of
-      // the one that was below (every thread is past its last read of it: the barrier behind phase 2).  (Loading it a
-      // phase early into registers, behind that barrier, was measured: 13 spilled registers, 2.09 vs 1.86 ms.)
-      slot = (it + 1) % 3;
-      const int fresh = (it + 2) % 3;
-      const long long gstart = (rowFirst - 1 + (long long)g.ny) * g.W;
-      for (int j = tid; j < len; j += NT) {
-        const long long gidx = gstart + j;
-        tile[fresh * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;
+    }
+    __syncthreads();
+    const long long planeBelow = (long long)((slot + 2) % 3 - slot) * TILE_PLANE, planeAbove = (long long)((slot + 1) % 3 - slot) * TILE_PLANE;
+    // where word (k, y, z) of this block is read from
+    auto at = [&](int k, int y, int z) -> WordPos {
+      if (TILED) {
+        const long long t = (long long)z * g.ny + y - rowFirst + 1;
+        return word_pos_tile(&tile[slot * TILE_PLANE + t * g.W + k], planeBelow, planeAbove, g, y, z, k);
       }
+      return word_pos(bits, g, y, z, k);
+    };
+    for (int i = tid; i < COUNT_WB; i += NT) {
+      const size_t gi = w0 + i;
+      u32 packed = 0;
+      if (gi < nwords) {
+        int k, y, z;
+        word_coords(g, gi, k, y, z);
+        const WordPos wp = at(k, y, z);
+        // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
+        // whole runs of such words, so whole waves take the short way)
+        if (wp.q[0] != 0) {
+          u64 F[6];
+          faces_at(wp, g, F);
+          int nQ = 0;
+#pragma unroll
+          for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
+          packed = (u32)nQ << 16;
+          // (one LDS atomic per word; one per wave -- ballot, popcount, broadcast -- was measured: no faster, 7 more
+          //  registers spilled)
+          if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
+        }
+      }
+      cnt[i] = packed;
     }
-  }
-  __syncthreads();
-  const long long planeBelow = (long long)((slot + 2) % 3 - slot) * TILE_PLANE, planeAbove = (long long)((slot + 1) % 3 - slot) * TILE_PLANE;
-  // where word (k, y, z) of this block is read from
-  auto at = [&](int k, int y, int z) -> WordPos {
-    if (TILED) {
-      const long long t = (long long)z * g.ny + y - rowFirst + 1;
-      return word_pos_tile(&tile[slot * TILE_PLANE + t * g.W + k], planeBelow, planeAbove, g, y, z, k);
-    }
-    return word_pos(bits, g, y, z, k);
-  };
-  for (int i = tid; i < COUNT_WB; i += NT) {
-    const size_t gi = w0 + i;
-    u32 packed = 0;
-    if (gi < nwords) {
+    __syncthreads();
+    const int nq = (MODE & 4) ? 0 : nQueued;
+    u32 errBits = 0;
+    for (int j = tid; j < nq; j += NT) {
+      const int i = queue[j];
+      const size_t gi = w0 + i;
       int k, y, z;
       word_coords(g, gi, k, y, z);
-      const WordPos wp = at(k, y, z);
-      // a word without inside voxels emits nothing: skip its six neighbour loads (outside regions are
-      // whole runs of such words, so whole waves take the short way)
-      if (wp.q[0] != 0) {
-        u64 F[6];
-        faces_at(wp, g, F);
-        int nQ = 0;
+      WordInfo w;
+      u32 unknown;
+      classify_word_at<false>(at(k, y, z), bits, occ, g, q1, w, unknown);
+      errBits |= unknown;
+      int nV = 0;
 #pragma unroll
-        for (int f = 0; f < 6; f++) nQ += popc64(F[f]);
-        packed = (u32)nQ << 16;
-        // (one LDS atomic per word; one per wave -- ballot, popcount, broadcast -- was measured: no faster, 7 more
-        //  registers spilled)
-        if (nQ) queue[atomicAdd(&nQueued, 1)] = (unsigned short)i;
-      }
+      for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
+      cnt[i] |= (u32)nV;
     }
-    cnt[i] = packed;
-  }
-  __syncthreads();
-  const int nq = (MODE & 4) ? 0 : nQueued;
-  u32 errBits = 0;
-  for (int j = tid; j < nq; j += NT) {
-    const int i = queue[j];
-    const size_t gi = w0 + i;
-    int k, y, z;
-    word_coords(g, gi, k, y, z);
-    WordInfo w;
-    u32 unknown;
-    classify_word_at<false>(at(k, y, z), bits, occ, g, q1, w, unknown);
-    errBits |= unknown;
-    int nV = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
-    cnt[i] |= (u32)nV;
-  }
-  if (errBits) atomicOr(&tot->err, errBits);
-  __syncthreads();
-  for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
-    const size_t gi = w0 + sg * 64 + lane;
-    const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
-    const u32 incl = wave_inclusive_sum(packed);
-    if (gi < nwords) prefix[gi] = incl - packed;
-    if (gi == g0) g0InSeg = incl - packed;
-    if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
-    // words that create vertices go to the global vertex-word queue IN ORDER (the point pass runs one lane per such
-    // word; a wave of it then owns one contiguous run of vertex ids): their places follow from these ballots
-    const u64 vm = __ballot((packed & 0xffffu) != 0u);
-    if (lane == 0) segVW[sg] = vm;
-  }
-  __syncthreads();
-  if (vqueue) {
-    if (wv == 1) {
-      // (wave 1, beside wave 0's segment scan below: 32 segment counts -> exclusive prefix, one global atomic per block)
-      const u32 n = lane < COUNT_WB / 64 ? (u32)__popcll(segVW[lane]) : 0u;
-      const u32 incl = wave_inclusive_sum(n);
-      if (lane < COUNT_WB / 64) segVWPre[lane] = incl - n;
-      const u32 total = __shfl(incl, 63, 64);
-      if (lane == 0 && total) vbase = atomicAdd(&tot->nVertexWords, total);
-    }
-  }
-  if (MODE & 2) continue;
-  if (wv == 0) {
-    // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
-    const u64 t = lane < COUNT_WB / 64 ? segTot[lane] : 0ull;
-    const u64 incl = wave_inclusive_sum2(t);
-    const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
-    const size_t seg = (w0 >> 6) + lane;
-    if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
-    if (g0 > 0 && (g0 >> COUNT_LG) == blk && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
-      const u32 in = g0InSeg;
-      tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
-    }
-    if (lane == COUNT_WB / 64 - 1) blockTot[blk] = incl;
-  }
-  if (vqueue) {
+    if (errBits) atomicOr(&tot->err, errBits);
     __syncthreads();
     for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
-      const u64 vm = segVW[sg];
-      if ((vm >> lane) & 1ull)
-        vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
+      const size_t gi = w0 + sg * 64 + lane;
+      const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
+      const u32 incl = wave_inclusive_sum(packed);
+      if (gi < nwords) prefix[gi] = incl - packed;
+      if (gi == g0) g0InSeg = incl - packed;
+      if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
+      // words that create vertices go to the global vertex-word queue IN ORDER (the point pass runs one lane per such
+      // word; a wave of it then owns one contiguous run of vertex ids): their places follow from these ballots
+      const u64 vm = __ballot((packed & 0xffffu) != 0u);
+      if (lane == 0) segVW[sg] = vm;
     }
-  }
+    __syncthreads();
+    if (vqueue) {
+      if (wv == 1) {
+        // (wave 1, beside wave 0's segment scan below: 32 segment counts -> exclusive prefix, one global atomic per block)
+        const u32 n = lane < COUNT_WB / 64 ? (u32)__popcll(segVW[lane]) : 0u;
+        const u32 incl = wave_inclusive_sum(n);
+        if (lane < COUNT_WB / 64) segVWPre[lane] = incl - n;
+        const u32 total = __shfl(incl, 63, 64);
+        if (lane == 0 && total) vbase = atomicAdd(&tot->nVertexWords, total);
+      }
+    }
+    if (MODE & 2) continue;
+    if (wv == 0) {
+      // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
+      const u64 t = lane < COUNT_WB / 64 ? segTot[lane] : 0ull;
+      const u64 incl = wave_inclusive_sum2(t);
+      const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
+      const size_t seg = (w0 >> 6) + lane;
+      if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
+      if (g0 > 0 && (g0 >> COUNT_LG) == blk && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
+        const u32 in = g0InSeg;
+        tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
+      }
+      if (lane == COUNT_WB / 64 - 1) blockTot[blk] = incl;
+    }
+    if (vqueue) {
+      __syncthreads();
+      for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
+        const u64 vm = segVW[sg];
+        if ((vm >> lane) & 1ull)
+          vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
+      }
+    }
   }   // the workgroup's next block
 }
 
