@@ -100,8 +100,12 @@ struct Tuning {
   int points_no_split = 0;    // 1: the point pass runs one lane per vertex word however short the queue
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
-  int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile, 0: from memory, -1: the tile when
-                              // the previous extraction on the context found vertices in a quarter of its words or more
+  int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile (in columns of 8 blocks where slices are
+                              // whole blocks), 2: the tile, one block per workgroup, >= 4: columns of that many, 0: from memory,
+                              // -1: the tile when the previous extraction on the context found vertices in a quarter of its words
+  // the walk: vertices per batch (0: 64 when the launch leaves wave slots empty, else 128), waves in the grid, idle lanes
+  // at which a wave refills (0: 16; 64 = only when empty, where the previous extraction's walks took under four passes
+  // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass
   int proj_chunk = 0, proj_waves = 16384, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
