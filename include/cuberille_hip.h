@@ -158,7 +158,9 @@ typedef struct {
   float ms_emit_cells;      /* quad / triangle scatter incl. the diagonal split (txx:278-332) */
   float ms_total;           /* ms_pass + the emit phase (points, projection, cells).  When cuberille_emit_points started the
                                vertex phase ahead of cuberille_emit, the two phases are timed as intervals of their own and
-                               added: the device's wait for the host's all-gather in between is in neither */
+                               added: the device's wait for the host's all-gather in between is in neither.  Inside
+                               cuberille_extract_device (no host turn in the middle) it is one interval from the first
+                               launch to the last: every further event would idle the stream for about 10 us */
   float ms_pass;            /* classify + count + scan: the pass over the volume.  cuberille_extract_host's chunked upload and
                                cuberille_extract_stream threshold every chunk as it lands, so for those two entries the
                                figure includes the ingestion; after cuberille_recount it is the second count alone */

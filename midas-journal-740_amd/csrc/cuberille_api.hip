@@ -90,6 +90,8 @@ struct cuberille_ctx {
   bool stagesTimed = false;              // the per-stage events of the running count/emit pair are being recorded
   bool lightTiming = false;              // a few million voxels at most: ONE event pair around the extraction (every event
                                          // between two kernels costs the stream about as much as such a volume's kernels)
+  bool oneCall = false;                  // inside cuberille_extract_device: no host turn between count and emit, so three
+                                         // events do (start, end of the pass, end): each one more idles the stream ~10 us
   Grid g{};
   Geo geo{};
   Params prm{};
@@ -702,7 +704,7 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   if (dyn && (!w.cmap || !w.headQ || !w.vqueue || c->tune.points_variant != 3))
     return fail(c, CUBERILLE_ERR_STATE, "internal: blind launch without the scratch tables");
   hipStream_t s = c->stream;
-  if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[4], s));
+  if (!c->lightTiming && (!c->oneCall || c->stagesTimed)) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   HIP_TRY(c, launch_heads(w, c->g, nV, totQ, dyn ? 1 : 0, s));
   HIP_TRY(c, launch_emit_points(w, c->g, c->geo, c->prm.q1, nV, nVW, c->tune, dyn ? 1 : 0, s));
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[5], s));
@@ -760,6 +762,10 @@ int finish_result(cuberille_ctx *c, cuberille_result *res) {
     // the caller took one); no pass figure
     HIP_TRY(c, hipEventElapsedTime(&b, c->ev[0], c->ev[7]));
     r.ms_pass = 0.f;
+  } else if (c->oneCall && !c->stagesTimed) {
+    // one call, no host turn in the middle: the pass, and everything behind it
+    HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&b, c->ev[2], c->ev[7]));
   } else {
     HIP_TRY(c, hipEventElapsedTime(&r.ms_pass, c->ev[0], c->ev[2]));
     if (c->pointsStartedEarly) {
@@ -811,7 +817,7 @@ int cuberille_emit_points(cuberille_ctx *c) {
   rc = emit_points_phase(c);
   if (rc) return rc;
   // the caller turns to the other ranks now: this phase gets its own end mark, cuberille_emit starts a second interval
-  if (!c->stagesTimed && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+  if (!c->stagesTimed && !c->lightTiming && !c->oneCall) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
   c->pointsStartedEarly = true;
   return CUBERILLE_OK;
 }
@@ -891,7 +897,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result 
   hipStream_t s = c->stream;
   // the vertex phase was started ahead of this call (cuberille_emit_points): the device may have idled since, waiting
   // for the host's all-gather -- the cell phase is timed as an interval of its own
-  if (c->pointsStartedEarly && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  if (c->pointsStartedEarly && !c->lightTiming && (!c->oneCall || c->stagesTimed)) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (planeCorners)
     HIP_TRY(c, hipMemcpyAsync(w.points + 3 * nV, c->extPts, planeCorners * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIP_TRY(c, launch_emit_cells(w, c->g, c->prm.triangles, c->prm.q1, point_id_offset, nQ, needPlane ? c->extIds : nullptr,
@@ -951,7 +957,7 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
     }
   }
   if (c->pointsEmitted) {
-    if (!c->stagesTimed && !c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+    if (!c->stagesTimed && !c->lightTiming && !c->oneCall) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
     c->pointsStartedEarly = true;
   }
   *dev_row = c->w.totals;
@@ -977,7 +983,7 @@ int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank,
     HIP_TRY(c, hipHostMalloc((void **)&c->hostRows, (size_t)n_ranks * sizeof(Totals), hipHostMallocDefault));
     c->hostRowsCap = (size_t)n_ranks;
   }
-  if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  if (!c->lightTiming && (!c->oneCall || c->stagesTimed)) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   // the cells, unless a flag stands somewhere (the kernel looks at the rows itself: every rank decides alike).  Sized
   // by the cover values (blind) or by this rank's counts; a rank whose vertex phase did not run launches nothing.
   if (blind || c->pointsEmitted) {
@@ -1038,6 +1044,12 @@ int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, 
   // once (every volume the reference ships is in the regime where the waits ARE the extraction time)
   const void *row = nullptr;
   size_t rowBytes = 0;
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  struct OneCall {
+    cuberille_ctx *c;
+    explicit OneCall(cuberille_ctx *ctx) : c(ctx) { c->oneCall = true; }
+    ~OneCall() { c->oneCall = false; }
+  } guard(c);
   int rc = cuberille_step_begin(c, img, dev_voxels, prm, slab, &row, &rowBytes);
   if (rc) return rc;
   rc = step_end_impl(c, row, 1, 0, slab ? slab->point_id_offset : 0, res);
