@@ -1094,7 +1094,10 @@ template <int SHIFT>
 __device__ __forceinline__ size_t locate_word_wave(const EmitArgs &a, const u32 *__restrict__ head, size_t nwords, u64 idx,
                                                    bool valid, u32 &within) {
   const int lane = threadIdx.x & 63;
-  const u64 first = __shfl(idx, 0, 64);          // lane 0 is always valid; first is a multiple of 64
+  // lane 0 is always valid; first is a multiple of 64 (taken through readfirstlane: the head's address is then
+  // wave-uniform and the load a scalar one -- this kernel is bound by its vector-memory instructions)
+  const u64 first = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)idx) |
+                    ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(idx >> 32)) << 32);
   size_t w0 = (size_t)head[first >> 6] & ~(size_t)3;   // (the words of the head's group before it produce earlier outputs)
   size_t found = 0;
   bool done = !valid;
