@@ -1106,7 +1106,11 @@ __device__ __forceinline__ size_t locate_word_wave(const EmitArgs &a, const u32 
     int t[4];
     if (w < nwords) {
       const uint4 pw = *reinterpret_cast<const uint4 *>(a.prefix + w);
-      const u64 base = seg_base<SHIFT>(a, w);
+      // (the window lies in one count block or two: their bases through wave-uniform addresses, scalar loads)
+      const size_t b0 = w0 >> COUNT_LG, b1 = b0 + 1 < a.nblk ? b0 + 1 : b0;
+      const u64 bb0 = a.blockBase[2 * b0 + (SHIFT ? 1 : 0)], bb1 = a.blockBase[2 * b1 + (SHIFT ? 1 : 0)];
+      const u64 sp = a.segPre[w >> 6];
+      const u64 base = ((w >> COUNT_LG) == b0 ? bb0 : bb1) + (SHIFT ? (sp >> 32) : (sp & 0xffffffffull));
       const u32 p4[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
       for (int i = 0; i < 4; i++) {
