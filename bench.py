@@ -61,6 +61,8 @@ WORKLOADS = {
 }
 
 
+# the rocprofv3 PMC summary (profiles/collect.sh) of exactly the configuration a line reports: workload, edge -> file
+PMC_FILES = {("marschner_lobb", 1024): "r3_pmc_hbm.csv", ("sphere", 512): "r3_config3_sphere512_pmc_hbm.csv"}
 PASS_KERNELS = ("k_classify_span<float", "k_classify_flat<float", "k_count<", "k_block_scan")
 
 
@@ -70,15 +72,15 @@ def measured_traffic(args, world, alg_bytes):
     the bytes of a 16 B/lane coalesced stream, so the sweep's is doubled -- MI355X_MICROARCH.md, HBM section; the
     count kernel's 8-byte accesses are uncalibrated and taken as counted).  Only valid for the configuration the
     profile was taken on; otherwise null."""
-    if world != 1 or args.size != 1024 or args.workload != "marschner_lobb":
+    name = PMC_FILES.get((args.workload, args.size))
+    if world != 1 or name is None or args.no_project or args.thr is not None:
         return None, None
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")))
-    if not files:
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
         return None, None
     total, seen = 0.0, set()
-    for row in csv.DictReader(open(files[-1])):
+    for row in csv.DictReader(open(path)):
         k = next((p for p in PASS_KERNELS if p in row["kernel"]), None)
         if k is None:
             continue
@@ -91,7 +93,7 @@ def measured_traffic(args, world, alg_bytes):
             seen.add((k, "W"))
     if not any(k.startswith("k_classify") for k, _ in seen) or ("k_count<", "F") not in seen:
         return None, None
-    return total * 1024.0, os.path.relpath(files[-1], ROOT)
+    return total * 1024.0, os.path.relpath(path, ROOT)
 
 
 def slab_probe(pkg, torch, ex, buf, n, dtype, prm, reps=20):
@@ -107,31 +109,41 @@ def slab_probe(pkg, torch, ex, buf, n, dtype, prm, reps=20):
     slab = pkg._abi.Slab(n, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO, None, None)
     sub = buf[lo:hi]
     wall = dev = 0.0
-    escaped = 0
+    escaped = retries = 0
     for i in range(reps + 2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ptr, _ = ex.step_begin(sub.data_ptr(), desc, prm, slab)
         res, done = ex.step_end(ptr, 1, 0)
         t1 = time.perf_counter()
-        if not done:                               # escaped walks: the probe has no neighbours to ask; finish without them
-            escaped = ex.escaped_count()
-            ex.reproject_escaped(buf.data_ptr(), 0, n)
+        if not done:
+            # CUBERILLE_RETRY: some flag in the row.  The probe has no neighbours to ask: continue with the synchronous
+            # calls as a driver would -- the vertex phase again unless quirk Q1 wants a source slice from below (then
+            # nothing occupied lies below in this volume: the count stands), escaped walks in the whole volume
+            retries += 1
+            info = ex.slab_info()
+            if not info.alias_source_below_buffer:
+                ex.emit_points()
+                escaped = ex.escaped_count()
+                if escaped:
+                    ex.reproject_escaped(buf.data_ptr(), 0, n)
             res = ex.emit(0)
         elif i >= 2:
             wall += t1 - t0
             dev += res.ms_total
-    k = max(reps if not escaped else 0, 1)
-    return {"slices": [a, b], "halo": [below + 1, above + 1], "points": int(res.n_points), "cells": int(res.n_cells),
+    k = max(reps - retries, 1)
+    return {"retries": retries, "slices": [a, b], "halo": [below + 1, above + 1], "points": int(res.n_points), "cells": int(res.n_cells),
             "wall_ms": round(wall / k * 1e3, 4), "device_ms": round(dev / k, 4),
             "wall_minus_device_ms": round(wall / k * 1e3 - dev / k, 4), "host_waits_per_step": 1,
             "halo_bytes_a_rank_would_receive": (below + above + 2) * n * n * int(np.dtype(dtype).itemsize),
             "escaped_walks": int(escaped)}
 
 
-def cpu_baseline(pkg, torch, args, device):
+def cpu_baseline(pkg, torch, args, device, gpu_mesh=None, gpu_iterations=None):
     """The oracle restatement of the reference ("port"), timed on this box's host cores on a
-    bounded sample of the same workload (the reference itself needs ITK)."""
+    bounded sample of the same workload (the reference itself needs ITK).
+    When the sample IS the bench volume (the default) the mesh the oracle just built is also held against the mesh of
+    the timed region, byte for byte: the second return value (parity_at_bench_size), None otherwise."""
     oracle = graft.load_oracle()
     oracle.build()
     n = args.cpu_sample
@@ -146,7 +158,22 @@ def cpu_baseline(pkg, torch, args, device):
                    gradient_threads=cores, faithful_cells=True)
     dt = time.perf_counter() - t0
     secs = m.info["seconds_gradient"] + m.info["seconds_sweep"]
-    return {
+    parity = None
+    if gpu_mesh is not None and n == args.size:
+        import hashlib
+        same_shape = gpu_mesh.points.shape == m.points.shape and gpu_mesh.cells.shape == m.cells.shape
+        same_cells = bool(same_shape and np.array_equal(gpu_mesh.cells, m.cells))
+        same_points = bool(same_shape and np.array_equal(gpu_mesh.points.view(np.uint32), m.points.view(np.uint32)))
+        parity = {"identical": bool(same_cells and same_points and gpu_iterations == m.info["proj_iterations"]),
+                  "cells_identical": same_cells, "point_bits_identical": same_points,
+                  "walk_passes": [int(gpu_iterations), int(m.info["proj_iterations"])],
+                  "points_sha256": hashlib.sha256(gpu_mesh.points.tobytes()).hexdigest()[:16],
+                  "cells_sha256": hashlib.sha256(gpu_mesh.cells.tobytes()).hexdigest()[:16],
+                  "oracle_points_sha256": hashlib.sha256(m.points.tobytes()).hexdigest()[:16],
+                  "oracle_cells_sha256": hashlib.sha256(m.cells.tobytes()).hexdigest()[:16],
+                  "what": "the mesh on the device after the timed region (downloaded) against the oracle's mesh of the same "
+                          "volume: cell ids and order, float bits of every coordinate, passes through the walk loop"}
+    return parity, {
         "value": round(n ** 3 / secs / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
         "sample": "%s %d^3 %s (%s, same generator and parameters); sweep single-threaded like the reference, "
                   "gradient pre-pass on %d threads like ITK; %.1f s gradient + %.1f s sweep, %d points / %d cells; "
@@ -397,18 +424,26 @@ def main():
             out["check_against_single"] = single_check
         if gather_ms is not None:
             out["gather_mesh_ms"] = round(gather_ms, 1)
+        mesh = None
         if world == 1:
             # outside the timed region, reported separately: copying the mesh to the host
             t0 = time.perf_counter()
             mesh = ex.download()
             out["d2h_mesh_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
             out["mesh_bytes"] = int(mesh.points.nbytes + mesh.cells.nbytes)
-            del mesh
         if world == 1 and not args.no_slab_probe and n >= 64:
-            out["slab_eighth_probe"] = slab_probe(pkg, torch, ex, buf, n, dtype, prm)
+            try:                     # a probe beside the measurement: whatever it runs into, the line is printed
+                out["slab_eighth_probe"] = slab_probe(pkg, torch, ex, buf, n, dtype, prm)
+            except Exception as e:   # noqa: BLE001
+                out["slab_eighth_probe"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        parity = None
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device)
+            parity, out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device, mesh, int(res.proj_iterations))
+            if parity is not None:
+                out["parity_at_bench_size"] = parity
         print(json.dumps(out), flush=True)
+        if parity is not None and not parity["identical"]:
+            raise SystemExit("bench: the mesh of the timed region differs from the oracle's at the bench size")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

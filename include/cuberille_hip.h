@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 9
+#define CUBERILLE_ABI_VERSION 10
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -229,6 +229,12 @@ int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, cuberille_resul
 int cuberille_step_begin(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
                          const cuberille_params *prm, const cuberille_slab *slab, const void **dev_row, size_t *row_bytes);
 int cuberille_step_end(cuberille_ctx *ctx, const void *dev_rows, int n_ranks, int rank, cuberille_result *res);
+/* A rank whose cuberille_step_begin FAILED has no row, yet its peers are on their way into the all-gather of the rows:
+ * this writes, into `capacity` bytes of HOST memory, a row that says "this rank failed" (*row_bytes: its size, the same
+ * as every row's).  The driver copies it to the device and contributes it to the gather in place of the row it does not
+ * have; every peer's cuberille_step_end then returns CUBERILLE_RETRY without writing a cell, and the ranks meet in the
+ * driver's synchronous protocol, where the failure is raised on all of them.  Needs no GPU and no context. */
+int cuberille_failed_row(void *host_row, size_t capacity, size_t *row_bytes);
 /* Optional, between the two: starts the part of the emit that needs no id offset -- head tables, vertex scatter,
  * projection -- and returns at once, so that the GPU works while the caller gathers the other ranks' counts;
  * cuberille_emit then only adds the cells.  A cuberille_recount after it voids what it started. */

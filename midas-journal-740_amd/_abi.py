@@ -26,9 +26,9 @@ EXPORTS = [
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
     "cuberille_minimum_halo", "cuberille_escaped_count", "cuberille_reproject_escaped", "cuberille_step_begin", "cuberille_step_end",
-    "cuberille_slice_counts",
+    "cuberille_slice_counts", "cuberille_failed_row",
 ]
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ImageDesc(C.Structure):
@@ -81,7 +81,7 @@ def build(force=False):
     srcs.append(os.path.join(_HERE, "..", "include", "cuberille_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j3", "-C", CSRC])
     return LIB_PATH
 
 
@@ -135,6 +135,7 @@ def lib():
                                        C.POINTER(C.c_size_t)]
     L.cuberille_step_end.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
     L.cuberille_slice_counts.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cuberille_failed_row.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cuberille_debug_h2d_seconds.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double)]
     L.cuberille_slice_bits_device.argtypes = [vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -143,6 +144,18 @@ def lib():
     L.cuberille_set_alias_plane.argtypes = [vp, vp, vp]
     _lib = L
     return L
+
+
+def failed_row():
+    """The row a rank whose cuberille_step_begin failed contributes to the all-gather of the rows (uint8 numpy array)."""
+    import numpy as np
+    n = C.c_size_t()
+    lib().cuberille_failed_row(None, 0, C.byref(n))
+    row = np.zeros(int(n.value), dtype=np.uint8)
+    rc = lib().cuberille_failed_row(C.c_void_p(row.ctypes.data), row.nbytes, C.byref(n))
+    if rc != OK:
+        raise CuberilleError(rc, "cuberille_failed_row")
+    return row
 
 
 def check(ctx, rc):

@@ -1037,6 +1037,15 @@ int cuberille_step_end(cuberille_ctx *c, const void *dev_rows, int n_ranks, int 
   return step_end_impl(c, dev_rows, n_ranks, rank, 0, res);
 }
 
+int cuberille_failed_row(void *host_row, size_t capacity, size_t *row_bytes) {
+  if (row_bytes) *row_bytes = sizeof(Totals);
+  if (!host_row || capacity < sizeof(Totals)) return CUBERILLE_ERR_ARGUMENT;
+  Totals t{};
+  t.err = ERRF_RANK_FAILED;        // counts of zero: the ranks above add nothing to their offsets, and write nothing anyway
+  std::memcpy(host_row, &t, sizeof t);
+  return CUBERILLE_OK;
+}
+
 int cuberille_extract_device(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels,
                              const cuberille_params *prm, const cuberille_slab *slab, cuberille_result *res) {
   // the one-wait step with this context as the only rank: the first extraction on a context reads its counts back

@@ -60,7 +60,9 @@ enum {
   ERRF_ALIAS_BELOW_BUFFER = 2,   // quirk Q1: the search for the source slice ran off the bottom of a slab buffer
   ERRF_CAPACITY = 4,             // cuberille_step_begin: the counts exceed what the blind launches / buffers were sized for
   ERRF_ESCAPE = 8,               // THIN_HALO: at least one walk left the buffer (Totals::nEscaped)
-  ERRF_ESCAPE_OVERFLOW = 16      // ... and more of them than the escape list holds
+  ERRF_ESCAPE_OVERFLOW = 16,     // ... and more of them than the escape list holds
+  ERRF_RANK_FAILED = 32          // never raised by a kernel: the row a driver contributes for a rank whose
+                                 // cuberille_step_begin failed (cuberille_failed_row)
 };
 
 // A count block owns COUNT_WB consecutive words of the flat raster order = 32 scan segments of 64 words.

@@ -11,6 +11,7 @@ falls back to a CPU implementation.
 """
 import collections
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -85,16 +86,37 @@ def make_params(iso, triangles=True, project=True, threshold=0.5, step=-1.0, rel
     """variant picks the branch of ProjectVertexToIsoSurface: the shipped one (txx:439-474) or one of the two the
     reference compiles out (USE_ADVANCED_PROJECTION txx:340-397, USE_LINESEARCH_PROJECTION txx:398-437; h:22-23).
     gradient: the shipped central differences, or USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21; txx:488-491; parity unpinned)."""
-    # (the 64-bit integer pixel types take the iso value as an integer: a double cannot hold it past 2^53)
-    iso_int = 0
+    # The 64-bit integer pixel types take the iso value as an integer (a double cannot hold it past 2^53): converted like
+    # the C cast the reference makes of it (m_IsoSurfaceValue IS an InputPixelType, h:180-181), i.e. truncated toward
+    # zero -- 100.5 is 100, as for every other integer pixel type.  A value no 64-bit type can hold (NaN, an infinity,
+    # beyond -2^63 .. 2^64 - 1) leaves `iso_int_exact` None, and the entry points refuse it for those pixel types.
+    exact = iso_int_of(iso)
+    iso_int = 0 if exact is None else ((exact + (1 << 63)) % (1 << 64)) - (1 << 63)   # uint64 above 2^63: the same 64 bits
+    prm = _abi.Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
+                      float(relax), int(max_steps), int(bool(q1)), int(variant), int(gradient), iso_int)
+    prm.iso_int_exact = exact
+    return prm
+
+
+def iso_int_of(iso):
+    """The iso value as the integer a C cast to a 64-bit integer pixel type gives: truncated toward zero; None when no
+    such type holds it."""
     try:
-        if isinstance(iso, (int, np.integer)) or float(iso) == int(iso):
-            iso_int = int(iso)
-    except (OverflowError, ValueError):
-        pass
-    iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
-    return _abi.Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
-                       float(relax), int(max_steps), int(bool(q1)), int(variant), int(gradient), iso_int)
+        v = int(iso) if isinstance(iso, (int, np.integer)) else math.trunc(float(iso))
+    except (OverflowError, ValueError):          # inf, NaN
+        return None
+    return v if -(1 << 63) <= v < (1 << 64) else None
+
+
+def check_iso(pixel_type, params):
+    """64-bit integer pixels: the iso value must be one the pixel type holds (the other integer types are range-checked
+    by the library against iso_value itself).  Parameters not made by make_params are taken as they are."""
+    if pixel_type not in (8, 9) or not hasattr(params, "iso_int_exact"):
+        return
+    v = params.iso_int_exact
+    lo, hi = (-(1 << 63), 1 << 63) if pixel_type == 8 else (0, 1 << 64)
+    if v is None or not (lo <= v < hi):
+        raise _abi.CuberilleError(_abi.ERR_ARGUMENT, "iso value is not representable in the pixel type")
 
 
 def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
@@ -152,6 +174,7 @@ class Extractor:
         """vol: mha.Volume in host memory.  Upload + extract (PCIe-inclusive)."""
         vox = np.ascontiguousarray(vol.voxels)
         desc = make_desc(vox.dtype, vol.dims, vol.spacing, vol.origin, vol.direction)
+        check_iso(int(desc.pixel_type), params)
         res = _abi.Result()
         _abi.check(self._ctx, self._lib.cuberille_extract_host(
             self._ctx, C.byref(desc), C.c_void_p(vox.ctypes.data), C.byref(params), C.byref(res)))
@@ -165,6 +188,7 @@ class Extractor:
         by source ends the call (CuberilleError ERR_SOURCE, the exception chained as its cause)."""
         nx, ny, _ = (int(v) for v in desc.dims)
         dtype = np.dtype(PIXEL_DTYPES[int(desc.pixel_type)])
+        check_iso(int(desc.pixel_type), params)
         raised = []
 
         def trampoline(_user, dst, z0, z1):
@@ -196,6 +220,7 @@ class Extractor:
             return self.extract_stream(desc, st, params), st
 
     def extract_device(self, dev_ptr, desc, params, slab=None):
+        check_iso(int(desc.pixel_type), params)
         res = _abi.Result()
         _abi.check(self._ctx, self._lib.cuberille_extract_device(
             self._ctx, C.byref(desc), C.c_void_p(dev_ptr), C.byref(params),
@@ -204,6 +229,7 @@ class Extractor:
         return res
 
     def count(self, dev_ptr, desc, params, slab=None):
+        check_iso(int(desc.pixel_type), params)
         npnt, ncell = C.c_uint64(), C.c_uint64()
         _abi.check(self._ctx, self._lib.cuberille_count(
             self._ctx, C.byref(desc), C.c_void_p(dev_ptr), C.byref(params),
@@ -223,6 +249,7 @@ class Extractor:
     def step_begin(self, dev_ptr, desc, params, slab=None):
         """Count and the offset-free part of the emit, launched back to back without waiting (cuberille_step_begin).
         Returns (device pointer, bytes) of this rank's row, to be all-gathered in rank order."""
+        check_iso(int(desc.pixel_type), params)
         p, n = C.c_void_p(), C.c_size_t()
         _abi.check(self._ctx, self._lib.cuberille_step_begin(
             self._ctx, C.byref(desc), C.c_void_p(dev_ptr), C.byref(params),

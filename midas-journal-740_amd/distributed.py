@@ -254,7 +254,7 @@ class ShardedExtractor:
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
-                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None):
+                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None, close_steps=False):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
@@ -270,6 +270,8 @@ class ShardedExtractor:
         (cuberille_step_begin / _end) -- the all-gather of the per-rank rows lands in device memory and the cell pass sums
         its id offset there; the host waits once per step.  A flag in any row (quirk Q1 across slabs, counts beyond the
         sizes guessed from the previous step, an escaped walk) sends every rank through the synchronous protocol.
+        close_steps: end every one-wait step in a gather of the ranks' outcomes, so that a failure inside
+        cuberille_step_end is raised on every rank (one more collective and host wait per step).
         bounds: the ranks' slices [(z0, z1)] (contiguous, in rank order) instead of slabs of equal thickness -- e.g.
         balanced_bounds(slice_work()) from a step on a similar volume."""
         from . import _abi
@@ -315,6 +317,8 @@ class ShardedExtractor:
         self.cross_slab_aliasing = cross_slab_aliasing
         self.counts = None
         self.device_offsets = bool(device_offsets)
+        self.close_steps = bool(close_steps)
+        self.force_step_path = False              # tests: the one-wait step over CPU tensors and gloo (a stand-in extractor)
         self._lib_stream = None                   # device_offsets: the library's work goes to a torch stream of ours
         self._rows = None
         self._lazy_counts = None
@@ -373,38 +377,54 @@ class ShardedExtractor:
             raise ValueError("these parameters let the projection reach %d slices; this ShardedExtractor was built "
                              "with a halo of %d (pass params= or halo= to its constructor)" % (need, self.halo))
         thin = self.thin is not None and bool(params.project_vertices) and int(params.projection_variant) == 0
-        if self.device_offsets and buf.is_cuda and hasattr(self.ex, "step_begin"):
+        if self.device_offsets and (buf.is_cuda or self.force_step_path) and hasattr(self.ex, "step_begin"):
             return self._extract_step(buf, params, thin)
         return self._extract_sync(buf, params, thin, held=0)
 
     def _extract_step(self, buf, params, thin):
         """One step with ONE host wait: exchange -> [count, vertex phase] -> all-gather of the rows in device memory ->
         cells with the offset summed on the device.  The library works on a stream of ours; events order it against
-        torch's current stream, where the collectives are enqueued."""
+        torch's current stream, where the collectives are enqueued.
+        A failure on one rank strands nobody: a rank whose cuberille_step_begin failed still joins the row all-gather,
+        with a row that carries the library's "this rank failed" flag (cuberille_failed_row) -- every peer's step_end
+        then comes back with CUBERILLE_RETRY, all ranks meet in the count all-gather of the synchronous protocol and
+        raise there together.  cuberille_step_end is the last thing of a step: a rank that fails in it raises, and the
+        others learn of it in the closing gather when close_steps is on (one more host-synchronised collective per step;
+        off by default: what can fail there -- the cell launch, the wait itself -- is a device fault that ends the
+        process anyway)."""
         import torch
         import torch.distributed as dist
+        from . import _abi
         dev = buf.device
-        if self._lib_stream is None:
+        cuda = dev.type == "cuda"                  # (CPU tensors: the gloo stand-ins of tests/test_distributed.py)
+        if cuda and self._lib_stream is None:
             self._lib_stream = torch.cuda.Stream(device=dev)
             self._ev = (torch.cuda.Event(), torch.cuda.Event())
             self.ex.use_stream(self._lib_stream)
-        cur, ls = torch.cuda.current_stream(), self._lib_stream
+        cur, ls = (torch.cuda.current_stream(), self._lib_stream) if cuda else (None, None)
         if thin:
             slab, desc, halo = self.thin_slab, self.thin_desc, self.thin
             base = buf[self.tlo - self.lo:self.thi - self.lo]
         else:
             slab, desc, halo, base = self.slab, self.desc, self.halo, buf
         keep = self._exchange(buf, halo, 0, slab)
-        if slab.voxels_ready_event is None:
+        if cuda and slab.voxels_ready_event is None:
             ls.wait_stream(cur)                    # (host-waited exchange: the buffer is ready, order the streams all the same)
-        ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
-        nw = nbytes // 8
-        row = _words_view(ptr, nw, dev)
-        if self._rows is None or self._rows.numel() != self.world * nw:
+        failed = None
+        try:
+            ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
+            nw = nbytes // 8
+            row = _words_view(ptr, nw, dev)
+        except _abi.CuberilleError as e:
+            failed = e
+            row = torch.from_numpy(_abi.failed_row().view(np.int64).copy()).to(dev)
+            nw = row.numel()
+        if self._rows is None or self._rows.numel() != self.world * nw or self._rows.device != dev:
             self._rows = torch.empty(self.world * nw, dtype=torch.int64, device=dev)
-        self._ev[0].record(ls)
-        cur.wait_event(self._ev[0])
-        if dist.get_backend(self.group) == "gloo":
+        if cuda:
+            self._ev[0].record(ls)
+            cur.wait_event(self._ev[0])
+        if cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal on one GPU: the rows go through the host (a wait that RCCL does not need)
             host = torch.empty(self.world * nw, dtype=torch.int64)
             dist.all_gather_into_tensor(host, row.cpu(), group=self.group)
@@ -413,22 +433,41 @@ class ShardedExtractor:
         else:
             dist.all_gather_into_tensor(self._rows, row, group=self.group)
         self.stats["collectives"] += 1
-        self._ev[1].record(cur)
-        ls.wait_event(self._ev[1])
-        res, done = self.ex.step_end(self._rows.data_ptr(), self.world, self.rank)
-        self.stats["host_syncs"] += 1
+        if cuda:
+            self._ev[1].record(cur)
+            ls.wait_event(self._ev[1])
+        res, done, end_failed = None, False, None
+        if failed is None:
+            try:
+                res, done = self.ex.step_end(self._rows.data_ptr(), self.world, self.rank)
+                self.stats["host_syncs"] += 1
+            except _abi.CuberilleError as e:
+                end_failed = e
         del keep
+        if self.close_steps:
+            flag = 1 if end_failed is not None else 0
+            ok = gather_counts(0, 0, dev, self.group, extra=(flag,))
+            self.stats["collectives"] += 1
+            if cuda:
+                self.stats["host_syncs"] += 1
+            self._raise_if_any_failed(ok[:, 2], "cuberille_step_end", end_failed)
+        elif end_failed is not None:
+            raise end_failed
         if done:
             # (the offsets were never on the host: gather_mesh reads the counts from the rows that step_end brought back)
             self.counts = None
             self._lazy_counts = (nw, 2 if int(params.generate_triangles) else 1)
             return res
-        # a flag somewhere: every rank goes on from its finished count with the host in the loop
-        return self._extract_sync(buf, params, thin, held=halo, resume=(int(res.n_points), int(res.n_cells)))
+        # a flag somewhere: every rank goes on from its finished count with the host in the loop (a rank whose step_begin
+        # failed has no count: it only carries its failure into the gather, where every rank raises)
+        return self._extract_sync(buf, params, thin, held=halo,
+                                  resume=(int(res.n_points), int(res.n_cells)) if failed is None else None, failed=failed)
 
-    def _extract_sync(self, buf, params, thin, held, resume=None):
+    def _extract_sync(self, buf, params, thin, held, resume=None, failed=None):
         """One step with the host in the loop: exchange, count, (vertex phase), all-gather of the counts, cells.
-        resume=(n_points, n_cells): the count is done already (a step that came back with CUBERILLE_RETRY)."""
+        resume=(n_points, n_cells): the count is done already (a step that came back with CUBERILLE_RETRY).
+        failed: this rank's cuberille_step_begin failed -- it has nothing to count or emit and goes straight to the
+        gather that tells the others."""
         import torch
         from . import _abi
         dev = buf.device
@@ -441,16 +480,18 @@ class ShardedExtractor:
         # a failure on one rank must not leave the others waiting in the all-gather: it travels with the counts
         n_p = n_c = 0
         n_esc = 0
-        info, failed = None, None
+        info = None
         try:
-            if resume is not None:
+            if failed is not None:
+                pass
+            elif resume is not None:
                 n_p, n_c = resume
             else:
                 n_p, n_c = self.ex.count(base.data_ptr(), desc, params, slab)
                 self.stats["host_syncs"] += 1
-            if self.check_aliasing and params.emulate_empty_slice_aliasing:
+            if failed is None and self.check_aliasing and params.emulate_empty_slice_aliasing:
                 info = self.ex.slab_info()
-            if info is None or info.alias_z < 0:
+            if failed is None and (info is None or info.alias_z < 0):
                 # nothing another rank says can change this rank's counts: the vertices are scattered and projected
                 # while the counts are gathered, only the cells wait for the id offsets
                 self.ex.emit_points()

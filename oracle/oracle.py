@@ -5,6 +5,7 @@ module (see oracle/cuberille_oracle.h).  It also holds a numpy closed-form
 counter used to cross-check the C++ sweep.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -95,13 +96,16 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches.  gradient: 0 the
     central differences of itk::GradientImageFilter, 1 USE_GRADIENT_RECURSIVE_GAUSSIAN (compiled out upstream too)."""
     img, keep = _image(vol, spacing, origin, direction)
-    iso_int = 0
+    # 64-bit integer pixels: the iso value as the C cast of the reference takes it (h:180-181), truncated toward zero
     try:
-        if isinstance(iso, (int, np.integer)) or float(iso) == int(iso):
-            iso_int = int(iso)
+        iso_int = int(iso) if isinstance(iso, (int, np.integer)) else math.trunc(float(iso))
     except (OverflowError, ValueError):
-        pass
-    iso_int = ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)      # uint64 values above 2^63 as the same 64 bits
+        iso_int = None
+    if keep.dtype in (np.dtype(np.int64), np.dtype(np.uint64)):
+        lo, hi = (-(1 << 63), 1 << 63) if keep.dtype == np.dtype(np.int64) else (0, 1 << 64)
+        if iso_int is None or not (lo <= iso_int < hi):
+            raise ValueError("iso value is not representable in the pixel type")
+    iso_int = 0 if iso_int is None else ((iso_int + (1 << 63)) % (1 << 64)) - (1 << 63)   # uint64 above 2^63: the same 64 bits
     prm = _Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
                   float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), int(gradient), iso_int)
     mesh = _Mesh()

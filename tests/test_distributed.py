@@ -265,11 +265,38 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         fake = types.SimpleNamespace(count=count, slab_info=slab_info, emit=emit, emit_points=emit_points, result=None,
                                      slice_bits_device=slice_bits_device, recount=recount, escaped_count=escaped_count,
                                      reproject_escaped=reproject_escaped)
+        if scenario.startswith("step"):
+            # the one-wait step (cuberille_step_begin / _end) with a stand-in: the row is the library's -- ten 64-bit words,
+            # counts first, the flags in the low half of word 6 -- in host memory here
+            import ctypes
+
+            def step_begin(ptr, desc, params, slab):
+                calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
+                if scenario == "step_begin_fails" and rank == 1:
+                    raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic step_begin failure")
+                row = np.zeros(10, dtype=np.int64)
+                row[0], row[1] = 100 + rank, 7 * (rank + 1)
+                calls["row"] = row
+                return row.ctypes.data, row.nbytes
+
+            def step_end(rows_ptr, n_ranks, r):
+                if scenario == "step_end_fails" and rank == 0:
+                    raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic step_end failure")
+                rows = np.frombuffer((ctypes.c_int64 * (10 * n_ranks)).from_address(rows_ptr), dtype=np.int64).reshape(n_ranks, 10)
+                res = types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
+                if (rows[:, 6] & 0xffffffff).any():
+                    calls["retry"] = True
+                    return res, False
+                calls["offsets"] = (int((rows[:r, 0] - rows[:r, 2]).sum()),)
+                return res, True
+            fake.step_begin, fake.step_end = step_begin, step_end
         prm = pkg.make_params(0.5)
         # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused, or,
         #  "recount_fails", taken up to the consumer's recount, which fails: every rank must raise, none may hang)
         sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm,
-                                cross_slab_aliasing=scenario == "recount_fails", thin_halo=scenario.startswith("thin"))
+                                cross_slab_aliasing=scenario == "recount_fails", thin_halo=scenario.startswith("thin"),
+                                close_steps=scenario == "step_end_fails")
+        sh.force_step_path = scenario.startswith("step")
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
         assert sh.thin == ((3, 3) if scenario.startswith("thin") else None)
         # every slice of the buffer says which slice it is: the exchanges must bring exactly the halo they are asked for
@@ -304,7 +331,8 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails", "thin", "thin_escape"])
+@pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails", "thin", "thin_escape",
+                                      "step_ok", "step_begin_fails", "step_end_fails"])
 def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
     (nobody is left waiting in the all-gather); quirk Q1 crossing the slab boundary is refused exactly when a rank
@@ -312,7 +340,14 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     port = _free_port()
     mp.spawn(_fake_worker, args=(2, port, scenario, str(tmp_path)), nprocs=2, join=True)
     rows = [np.load(str(tmp_path / ("r%d.npy" % r))) for r in range(2)]
-    if scenario in ("ok", "alias_nothing_below", "thin", "thin_escape"):
+    if scenario == "step_begin_fails":
+        # (round-3 advisor finding) the rank whose cuberille_step_begin failed joins the row all-gather with the library's
+        # "this rank failed" row: its peer's step_end says RETRY, both meet in the count all-gather and raise there
+        assert all("cuberille_count failed on rank(s) [1]" in r[0] for r in rows)
+        assert "synthetic step_begin failure" in rows[1][0]
+    elif scenario == "step_end_fails":
+        assert all("cuberille_step_end failed on rank(s) [0]" in r[0] for r in rows)     # close_steps: raised everywhere
+    elif scenario in ("ok", "alias_nothing_below", "thin", "thin_escape", "step_ok"):
         assert rows[0][0] == "" and rows[1][0] == ""
         assert rows[0][1] == "(0,)" and rows[1][1] == "(100,)"
         if scenario.startswith("thin"):                    # 3 + 3 slices around the owned range, flagged as a thin slab

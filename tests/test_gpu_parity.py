@@ -223,6 +223,36 @@ def test_512_sphere_properties(pkg, extractor):
     assert dist.max() < 0.06                    # thr 0.05 on the trilinear field ~ exact SDF to <0.01
 
 
+def _host_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def test_512_sphere_matches_oracle_at_bench_parameters(pkg, oracle, extractor):
+    """BASELINE.json configs[2] at FULL size with the bench's parameters (`bench.py --workload sphere --size 512`:
+    triangles + projection, thr 0.05), byte for byte against the oracle -- ids, cell order, the split of every quad,
+    float bits of every coordinate, passes through the walk loop -- and the quad form too.  The launch shapes of this
+    size (whole-word rows, 1024 count blocks, 128-vertex batches of the walk) are the ones compared, not forced ones."""
+    import torch
+    n = 512
+    vol = pkg.volumes.sphere_sdf(n, xp=torch, device="cuda")
+    host = vol.cpu().numpy()
+    desc = pkg.make_desc(np.float32, (n, n, n))
+    for tri in (1, 0):
+        kw = dict(triangles=tri, project=True, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
+        prm = pkg.make_params(0.0, **kw)
+        for _ in range(2):          # the second extraction on a context launches blindly, sized by the first
+            res = extractor.extract_device(vol.data_ptr(), desc, prm)
+        mesh = extractor.download()
+        ref = oracle.run(host, 0.0, gradient_threads=_host_threads(), **kw)
+        assert len(ref.points) > 700000
+        assert_same_mesh(mesh, ref)
+        assert int(res.proj_iterations) == ref.info["proj_iterations"]
+        assert (int(res.proj_stop_threshold), int(res.proj_stop_steps)) == (ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"])
+
+
 def _read_vtk_polydata(path):
     tok = open(path).read().split()
     i = tok.index("POINTS")
@@ -544,6 +574,34 @@ def test_1024_marschner_lobb_properties(pkg, extractor):
     assert np.array_equal(np.concatenate(pts).view(np.uint32), tri.points.view(np.uint32))
 
 
+def test_1024_marschner_lobb_matches_oracle_at_bench_parameters(pkg, oracle, extractor):
+    """BASELINE.json configs[3], the bench workload itself at FULL size and with the bench's parameters (iso 0.5,
+    triangles + projection, thr 0.002, step 0.25, relax 0.95, 50 steps): the HIP mesh byte for byte against the oracle's
+    -- 11.1 M points, 22.3 M triangles: ids, order, shorter-diagonal split, float bits, passes through the walk loop.
+    This is where k_classify_span, the 128-vertex batches and blind launches of the walk and the prefixes of a
+    4.3 GB volume run in their production shapes.  (The oracle takes about half a minute here; the volume is generated
+    once, on the GPU, and both sides read the same bytes: sin/cos are not bit-portable.)"""
+    import torch
+    n = 1024
+    vol = torch.cat([pkg.volumes.marschner_lobb(n, a, min(a + 64, n), xp=torch, device="cuda") for a in range(0, n, 64)])
+    torch.cuda.synchronize()        # the library runs on a stream of its own: the generator must be done (or hand it an event)
+    desc = pkg.make_desc(np.float32, (n, n, n))
+    kw = dict(triangles=True, project=True, threshold=0.002, step=0.25, relax=0.95, max_steps=50)
+    prm = pkg.make_params(0.5, **kw)
+    for _ in range(2):              # first: counts waited for; second: launched blindly from the first one's sizes
+        res = extractor.extract_device(vol.data_ptr(), desc, prm)
+    mesh = extractor.download()
+    host = vol.cpu().numpy()
+    del vol
+    torch.cuda.empty_cache()
+    ref = oracle.run(host, 0.5, gradient_threads=_host_threads(), **kw)
+    del host
+    assert (len(ref.points), len(ref.cells)) == (11130818, 22261632)
+    assert_same_mesh(mesh, ref)
+    assert int(res.proj_iterations) == ref.info["proj_iterations"]
+    assert (int(res.proj_stop_threshold), int(res.proj_stop_steps)) == (ref.info["proj_stop_threshold"], ref.info["proj_stop_steps"])
+
+
 def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, volumes):
     """cuberille_slab.halo_ready_event: the halo slices of the buffer are still being written (here by a
     copy on a side stream, in production by the RCCL exchange) when cuberille_count is called; the library
@@ -716,6 +774,41 @@ def test_2048_noise_u8_config5_full_size(pkg, extractor):
         poff += n_p
         coff += n_c
     assert (poff, coff) == (want_pts, 2 * want_quads)
+
+
+def test_2048x2048_noise_u8_slab_of_config5_matches_oracle(pkg, oracle, extractor):
+    """BASELINE.json configs[4]'s field in its full-size launch shapes against the ORACLE: a whole volume of 2048 x 2048 x
+    160 uint8 voxels of the same generator (640 MiB: k_classify_span<unsigned char>; rows of 32 words, slices of 32 count
+    blocks: the LDS-tiled count in columns, which the density of the first extraction selects for the second; more than
+    2^24 vertices, 40 M triangles), iso 128, the bench's parameters -- ids, order, split and float bits, byte for byte.
+    The oracle's gradient image of the full 2048^3 would be 103 GB; 160 slices are 8 GB."""
+    import torch
+    nx = ny = 2048
+    nz = 160
+    vol = torch.cat([pkg.volumes.gradient_noise(nx, ny, nz, a, min(a + 32, nz), xp=torch, device="cuda") for a in range(0, nz, 32)])
+    torch.cuda.synchronize()        # the library runs on a stream of its own: the generator must be done
+    desc = pkg.make_desc(np.uint8, (nx, ny, nz))
+    kw = dict(triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+    prm = pkg.make_params(128, **kw)
+    meshes = []
+    for variant in (0, 1):          # the count from memory / from the LDS tile in columns (the production form of this field)
+        extractor.debug_option("count_variant", variant)
+        res = extractor.extract_device(vol.data_ptr(), desc, prm)
+        meshes.append(extractor.download())
+    extractor.debug_option("defaults", 0)
+    res = extractor.extract_device(vol.data_ptr(), desc, prm)       # and whatever the context's history picks
+    mesh = extractor.download()
+    for m in meshes:
+        assert np.array_equal(m.cells, mesh.cells) and np.array_equal(m.points.view(np.uint32), mesh.points.view(np.uint32))
+    del meshes
+    host = vol.cpu().numpy()
+    del vol
+    torch.cuda.empty_cache()
+    ref = oracle.run(host, 128, gradient_threads=_host_threads(), **kw)
+    del host
+    assert len(ref.points) > (1 << 24)
+    assert_same_mesh(mesh, ref)
+    assert int(res.proj_iterations) == ref.info["proj_iterations"]
 
 
 def test_hip_path_reproduces_committed_mesh_digests(pkg, extractor, volumes):
@@ -1698,6 +1791,15 @@ def test_64bit_integer_pixels_match_oracle(pkg, oracle, extractor, dtype):
         a = run_gpu(pkg, extractor, pkg.Volume(small), 100, **kw)
         assert_same_mesh(a, oracle.run(small, 100, **kw))
         assert_same_mesh(a, oracle.run(small.astype(np.int32), 100, **kw))
+        # a fractional iso value is cast like the reference's InputPixelType member (h:180-181): truncated toward zero,
+        # as for the narrower integer types -- 100.5 is 100 (round-3 advisor finding: it used to become 0)
+        b = run_gpu(pkg, extractor, pkg.Volume(small), 100.5, **kw)
+        assert_same_mesh(b, a)
+        assert_same_mesh(b, oracle.run(small, 100.5, **kw))
+        assert_same_mesh(b, oracle.run(small.astype(np.int32), 100.5, **kw))
+        for bad in (float("nan"), float("inf"), 2.0 ** 64, -2.0 ** 63 - 4096.0, -1.0 if dtype == np.uint64 else 2.0 ** 63):
+            with pytest.raises(pkg._abi.CuberilleError):
+                run_gpu(pkg, extractor, pkg.Volume(small), bad, **kw)
         # magnitudes where (float)pixel and (double)pixel round: a smooth field scaled to 2^55, low bits noisy
         zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
         f = np.sin(zz * 0.9) + np.sin(yy * 0.7 + 1.0) + np.sin(xx * 0.3 + 2.0)

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 9
+    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_the_header(pkg):
@@ -331,3 +331,31 @@ def test_host_walk_through_a_nonlinear_interpolator(pkg, oracle, tmp_path, threa
     # ... and it is not the linear interpolator's walk
     lin = oracle.run(vol, 0.0, triangles=False, project=True, **kw)
     assert not np.array_equal(lin.points, got)
+
+
+def test_iso_value_of_64bit_pixels_is_cast_like_the_reference(pkg, oracle):
+    """m_IsoSurfaceValue is an InputPixelType (h:180-181): a fractional value handed to a `long` image is truncated
+    toward zero by the C cast, like for every narrower integer type -- not dropped to 0 (round-3 advisor finding).  Values
+    no 64-bit type holds are refused by the entry points; the oracle's loader follows the same rule."""
+    prm = pkg.make_params(100.5)
+    assert prm.iso_value_int == 100 and prm.iso_value == 100.5
+    assert pkg.make_params(-100.5).iso_value_int == -100
+    assert pkg.make_params(2 ** 63 + 5).iso_value_int == (2 ** 63 + 5) - 2 ** 64      # uint64: the same 64 bits
+    assert pkg.make_params((3 << 55) + 1).iso_value_int == (3 << 55) + 1               # not a double: travels as an integer
+    from midas_journal_740_amd.cuberille import check_iso
+    for code, bad in ((8, float("nan")), (8, float("inf")), (8, 2.0 ** 63), (8, -2.0 ** 63 - 4096.0), (9, -1.0), (9, 2.0 ** 64)):
+        with pytest.raises(pkg._abi.CuberilleError) as e:
+            check_iso(code, pkg.make_params(bad))
+        assert e.value.code == pkg._abi.ERR_ARGUMENT
+    check_iso(8, pkg.make_params(-2.0 ** 63))
+    check_iso(9, pkg.make_params(2 ** 64 - 1))
+    check_iso(6, pkg.make_params(float("nan")))     # a float image takes any iso value (txx:139-141: every compare false)
+    rng = np.random.default_rng(5)
+    small = rng.integers(0, 200, size=(6, 7, 9))
+    kw = dict(triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=30)
+    a = oracle.run(small.astype(np.int64), 100.5, **kw)
+    for other in (oracle.run(small.astype(np.int64), 100, **kw), oracle.run(small.astype(np.int32), 100.5, **kw),
+                  oracle.run(small.astype(np.uint64), 100.9, **kw)):
+        assert np.array_equal(a.cells, other.cells) and np.array_equal(a.points.view(np.uint32), other.points.view(np.uint32))
+    with pytest.raises(ValueError):
+        oracle.run(small.astype(np.uint64), -1.0, **kw)
