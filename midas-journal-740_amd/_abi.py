@@ -26,7 +26,7 @@ EXPORTS = [
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
     "cuberille_minimum_halo", "cuberille_escaped_count", "cuberille_reproject_escaped", "cuberille_step_begin", "cuberille_step_end",
-    "cuberille_slice_counts", "cuberille_failed_row",
+    "cuberille_slice_counts", "cuberille_failed_row", "cuberille_warm_up", "cuberille_mesh_host",
 ]
 ABI_VERSION = 10
 
@@ -122,6 +122,7 @@ def lib():
     L.cuberille_emit_points.argtypes = [vp]
     L.cuberille_mesh_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cuberille_mesh_download.argtypes = [vp, vp, vp]
+    L.cuberille_mesh_host.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cuberille_debug_bits.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_slice_occupancy.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_write_vtk_buffers.argtypes = [C.c_char_p, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int]
@@ -135,6 +136,7 @@ def lib():
                                        C.POINTER(C.c_size_t)]
     L.cuberille_step_end.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
     L.cuberille_slice_counts.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cuberille_warm_up.argtypes = [vp, C.POINTER(ImageDesc), C.POINTER(Params)]
     L.cuberille_failed_row.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cuberille_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.cuberille_debug_h2d_seconds.argtypes = [vp, C.c_size_t, C.POINTER(C.c_double)]

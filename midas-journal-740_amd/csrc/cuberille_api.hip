@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -47,6 +48,35 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Host memory of the context's own (cuberille_mesh_host): anonymous pages, 2 MiB aligned and advised as huge pages where
+// the system has them; kept and re-used across extractions, grown with head-room.
+struct HostBuf {
+  void *p = nullptr, *base = nullptr;
+  size_t cap = 0, mapped = 0;
+  bool reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    release();
+    const size_t huge = 2u << 20;
+    size_t want = bytes + bytes / 8;
+    want = (want + huge - 1) & ~(huge - 1);
+    void *m = mmap(nullptr, want + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return false;
+    base = m;
+    mapped = want + huge;
+    p = (void *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+    cap = want;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, cap, MADV_HUGEPAGE);
+#endif
+    return true;
+  }
+  void release() {
+    if (base) (void)munmap(base, mapped);
+    p = base = nullptr;
+    cap = mapped = 0;
+  }
+};
+
 }  // namespace
 
 struct cuberille_ctx {
@@ -55,6 +85,8 @@ struct cuberille_ctx {
   std::string err;
   DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue, escList;
   DevBuf gradImg, rgA, rgB, rgScratch;   // gradient_variant 1: the gradient image and what its passes go through
+  HostBuf hostPoints, hostCells;         // cuberille_mesh_host: the last mesh in host memory of the context's own
+  bool hostMeshValid = false;            // ... holds the mesh of the last emit
   Totals *hostTotals = nullptr;          // pinned
   uint32_t *hostOcc = nullptr;           // pinned mirror of the per-slice occupancy of the last slab count
   size_t hostOccCap = 0;
@@ -73,6 +105,7 @@ struct cuberille_ctx {
   bool pointsStartedEarly = false;       // cuberille_emit_points ran ahead of cuberille_emit (two device intervals to add up)
   bool escapeChecked = false;            // THIN_HALO: the number of escaped walks of the current vertex phase has been read back
   // cuberille_step_begin / _end: what the previous extraction on this context produced sizes the blind launches
+  bool warm = false;                     // cuberille_warm_up has run its toy extraction
   bool haveHistory = false;
   u64 histV = 0, histQ = 0;
   u32 histVW = 0;
@@ -237,6 +270,8 @@ void cuberille_destroy(cuberille_ctx *c) {
                     &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->escList,
                     &c->gradImg, &c->rgA, &c->rgB, &c->rgScratch};
   for (DevBuf *b : bufs) b->release();
+  c->hostPoints.release();
+  c->hostCells.release();
   if (c->hostTotals) (void)hipHostFree(c->hostTotals);
   if (c->hostOcc) (void)hipHostFree(c->hostOcc);
   if (c->hostRows) (void)hipHostFree(c->hostRows);
@@ -360,6 +395,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->counted = false;
   c->pointsEmitted = false;
   c->haveMesh = false;
+  c->hostMeshValid = false;
   c->stepMode = 0;
   c->aliasBelowBuffer = false;
   c->aliasMustResolve = false;
@@ -1226,6 +1262,79 @@ int cuberille_extract_stream(cuberille_ctx *c, const cuberille_image_desc *img, 
   return cuberille_emit(c, 0, res);
 }
 
+int cuberille_warm_up(cuberille_ctx *c, const cuberille_image_desc *img, const cuberille_params *prm) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  cuberille_params dflt{};
+  dflt.iso_value = 1.0; dflt.generate_triangles = 1; dflt.project_vertices = 1; dflt.distance_threshold = 0.5;
+  dflt.step_length = -1.0; dflt.relaxation = 0.95; dflt.max_steps = 50; dflt.emulate_empty_slice_aliasing = 1;
+  dflt.iso_value_int = 1;
+  if (!c->warm) {
+    // one tiny extraction: the first launch of any kernel loads the library's code objects, the first copies and events
+    // set up the runtime's queues.  8 x 8 x 8 voxels with a 4 x 4 x 4 block inside; nothing of it stays on the context.
+    unsigned char tiny[512];
+    for (int z = 0; z < 8; z++)
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) tiny[(z * 8 + y) * 8 + x] = (x >= 2 && x < 6 && y >= 2 && y < 6 && z >= 2 && z < 6) ? 200 : 0;
+    cuberille_image_desc d{};
+    d.pixel_type = CUBERILLE_PIX_U8;
+    for (int i = 0; i < 3; i++) { d.dims[i] = 8; d.spacing[i] = 1.0; d.direction[i * 4] = 1.0; }
+    cuberille_params p = dflt;
+    p.iso_value = 100.0;
+    cuberille_result r{};
+    for (int i = 0; i < 2; i++) {            // twice: the second one takes the blind launches of the one-wait step
+      const int rc = cuberille_extract_host(c, &d, tiny, &p, &r);
+      if (rc) return rc;
+    }
+    // the runtime sets up its staging for copies from and to PAGEABLE memory at the first copy that needs it (measured
+    // through the reference's driver: 7.2 ms inside the first hipMemcpyAsync of nucleon.mha's 69 KB, profiles/
+    // r4_cold_update.log): one round trip of a size that takes its staging buffers, one of a size it pins in place
+    {
+      std::vector<char> host(8u << 20, 1);
+      HIP_TRY(c, c->voxOwn.reserve(host.size()));
+      const size_t sizes[2] = {256u << 10, host.size()};
+      for (size_t n : sizes) {
+        HIP_TRY(c, hipMemcpyAsync(c->voxOwn.p, host.data(), n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(host.data(), c->voxOwn.p, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+      }
+    }
+    c->haveHistory = false;                  // (sizes of a toy volume: the first real extraction reads its own counts)
+    c->haveMesh = false;
+    c->counted = false;
+    c->warm = true;
+  }
+  if (!img) return CUBERILLE_OK;
+  if (pixel_size(img->pixel_type) == 0) return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown pixel type");
+  for (int i = 0; i < 3; i++)
+    if (img->dims[i] < 1 || img->dims[i] > 0x7fffffffLL) return fail(c, CUBERILLE_ERR_ARGUMENT, "image dimensions out of range");
+  (void)prm;
+  // the buffers whose size follows from the description (count_prepare, emit_points_phase, cuberille_extract_host); a
+  // reservation that fails here is asked for again, and reported, by the extraction
+  const size_t nx = (size_t)img->dims[0], ny = (size_t)img->dims[1], nz = (size_t)img->dims[2];
+  const size_t W = (nx + 63) / 64, nwords = nz * ny * W, nseg = (nwords + 63) / 64, nblk = (nwords + COUNT_WB - 1) / COUNT_WB;
+  const size_t bytes = nx * ny * nz * pixel_size(img->pixel_type);
+  bool ok = c->voxOwn.reserve(bytes) == hipSuccess;
+  ok = ok && c->bits.reserve((nwords + ny * W) * sizeof(u64)) == hipSuccess;
+  ok = ok && c->occ.reserve(sizeof(Totals) + nz * sizeof(u32)) == hipSuccess;
+  ok = ok && c->prefix.reserve((nwords + 4) * sizeof(u32)) == hipSuccess;
+  ok = ok && c->segPre.reserve(nseg * sizeof(u64)) == hipSuccess;
+  ok = ok && c->blockTot.reserve(nblk * sizeof(u64)) == hipSuccess;
+  ok = ok && c->blockBase.reserve(nblk * 2 * sizeof(u64)) == hipSuccess;
+  if (ok && nx % 64 != 0) ok = c->flatBits.reserve((nwords + 32) * sizeof(u64)) == hipSuccess;
+  if (ok && nwords < 0xffffffffULL && !c->tune.no_vqueue) ok = c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess;
+  if (ok && !c->tune.no_cmap) {
+    const size_t mapBytes = c->tune.cmap_linear ? (nx + 1) * (ny + 1) * (nz + 2) * sizeof(u32)
+                          : ((nx + 4) >> 2) * ((ny + 4) >> 2) * ((nz + 3) >> 1) * 32 * sizeof(u32);
+    ok = c->cmap.reserve(mapBytes) == hipSuccess;
+  }
+  if (!ok) (void)hipGetLastError();
+  // the pinned staging ring: a chunked upload (volumes of a GiB and more) and the download of a mesh of more than 128 MiB
+  // go through it; a volume of 64 MiB can carry such a mesh
+  if (ok && bytes >= (64ull << 20)) (void)ensure_staging(c, 32u << 20);
+  return CUBERILLE_OK;
+}
+
 int cuberille_slice_counts(cuberille_ctx *c, uint64_t *points, uint64_t *quads, size_t n_slices) {
   if (!c || (!points && !quads)) return CUBERILLE_ERR_ARGUMENT;
   if (!c->counted && !c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no count on this context");
@@ -1408,17 +1517,33 @@ int cuberille_mesh_download(cuberille_ctx *c, float *points, uint64_t *cells) {
   return CUBERILLE_OK;
 }
 
+int cuberille_mesh_host(cuberille_ctx *c, float **points, uint64_t **cells) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");
+  const cuberille_result &r = c->res;
+  if (!c->hostMeshValid) {
+    const size_t pb = (size_t)r.n_points * 3 * sizeof(float), cb = (size_t)r.n_cells * r.verts_per_cell * sizeof(uint64_t);
+    if (!c->hostPoints.reserve(pb ? pb : 1) || !c->hostCells.reserve(cb ? cb : 1))
+      return fail(c, CUBERILLE_ERR_HIP, "cuberille_mesh_host: out of host memory");
+    const int rc = cuberille_mesh_download(c, (float *)c->hostPoints.p, (uint64_t *)c->hostCells.p);
+    if (rc) return rc;
+    c->hostMeshValid = true;
+  }
+  if (points) *points = (float *)c->hostPoints.p;
+  if (cells) *cells = (uint64_t *)c->hostCells.p;
+  return CUBERILLE_OK;
+}
+
 int cuberille_mesh_write_vtk(cuberille_ctx *c, const char *path, int n_threads) {
   if (!c || !path) return CUBERILLE_ERR_ARGUMENT;
   if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");
   if (c->slabMesh) return fail(c, CUBERILLE_ERR_STATE, "a slab mesh is not self-contained: concatenate the rank buffers and call cuberille_write_vtk_buffers");
   const cuberille_result &r = c->res;
-  std::vector<float> pts(3 * r.n_points);
-  std::vector<uint64_t> cells((size_t)r.verts_per_cell * r.n_cells);
-  const int rc = cuberille_mesh_download(c, pts.data(), cells.data());
+  float *pts = nullptr;
+  uint64_t *cells = nullptr;
+  const int rc = cuberille_mesh_host(c, &pts, &cells);
   if (rc != CUBERILLE_OK) return rc;
-  const int wr = cuberille_write_vtk_buffers(path, pts.data(), r.n_points, cells.data(), r.n_cells, r.verts_per_cell,
-                                             n_threads);
+  const int wr = cuberille_write_vtk_buffers(path, pts, r.n_points, cells, r.n_cells, r.verts_per_cell, n_threads);
   if (wr != CUBERILLE_OK) return fail(c, wr, std::string("cannot write ") + path);
   return CUBERILLE_OK;
 }

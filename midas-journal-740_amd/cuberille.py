@@ -155,6 +155,12 @@ class Extractor:
         except Exception:
             pass
 
+    def warm_up(self, desc=None, params=None):
+        """cuberille_warm_up: load the code objects and, with an image description, reserve the workspace for such a volume
+        -- what the first extraction on a fresh context would otherwise pay inside its own call."""
+        _abi.check(self._ctx, self._lib.cuberille_warm_up(self._ctx, C.byref(desc) if desc is not None else None,
+                                                          C.byref(params) if params is not None else None))
+
     def use_torch_stream(self):
         """Order this context's work on torch's current stream."""
         torch = _torch()
@@ -304,6 +310,18 @@ class Extractor:
             self._ctx, C.c_void_p(pts.ctypes.data), C.c_void_p(cells.ctypes.data)))
         return Mesh(pts, cells)
 
+    def mesh_host(self):
+        """The last mesh part in host memory of the CONTEXT (cuberille_mesh_host): numpy views, valid until the next count
+        or extraction on this extractor -- copy what must live longer.  The context keeps the memory across extractions
+        (huge pages where the system has them), so this is the fast way to the host for a series of meshes."""
+        res = self.result
+        npnt, ncell, vpc = int(res.n_points), int(res.n_cells), int(res.verts_per_cell)
+        pp, cp = C.c_void_p(), C.c_void_p()
+        _abi.check(self._ctx, self._lib.cuberille_mesh_host(self._ctx, C.byref(pp), C.byref(cp)))
+        pts = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_float)), shape=(max(npnt * 3, 1),))[:npnt * 3].reshape(npnt, 3)
+        cells = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_uint64)), shape=(max(ncell * vpc, 1),))[:ncell * vpc].reshape(ncell, vpc)
+        return Mesh(pts, cells)
+
     def write_vtk(self, path, threads=0):
         """Download the last whole-volume mesh and write it as legacy-ASCII VTK POLYDATA."""
         _abi.check(self._ctx, self._lib.cuberille_mesh_write_vtk(self._ctx, os.fsencode(path), int(threads)))
@@ -409,6 +427,21 @@ class CuberilleImageToMeshFilter:
         self._variant = PROJECT_DEFAULT           # h:22-23: both alternative branches are compiled out
         self._gradient = GRADIENT_CENTRAL         # h:21: and so is the recursive-Gaussian gradient
         self.last_result = None
+        # like the C++ drop-in: the GPU context and the code objects are set up when the filter is made, not inside the
+        # first Update() (the reference's driver times one cold Update(), test:158-160); silent without a device --
+        # Update() tries again and raises
+        self._acquire(False)
+
+    def _acquire(self, must):
+        if self._extractor is None:
+            try:
+                self._extractor = Extractor(self._device)
+                self._extractor.warm_up()
+            except (_abi.CuberilleError, ImportError, OSError):
+                self._extractor = None
+                if must:
+                    raise
+        return self._extractor is not None
 
     # h:184 / txx:53-56
     def SetInput(self, image):
@@ -417,6 +450,8 @@ class CuberilleImageToMeshFilter:
         self._input = image
         self._dtype = image.voxels.dtype
         self._threshold = _clamp(self._threshold_asked, 0.0, _pixel_max(self._dtype))
+        if self._acquire(False) and self._dtype in PIXEL_CODES:
+            self._extractor.warm_up(make_desc(self._dtype, image.dims, image.spacing, image.origin, image.direction))
 
     # h:180-181
     def SetIsoSurfaceValue(self, v):
@@ -502,8 +537,7 @@ class CuberilleImageToMeshFilter:
         if self._input is None:
             # the ITK pipeline throws for a missing required input (txx:33)
             raise RuntimeError("CuberilleImageToMeshFilter: input 0 is required but not set")
-        if self._extractor is None:
-            self._extractor = Extractor(self._device)
+        self._acquire(True)
         vol = self._input
         if self._step < 0.0:                      # txx:82-85, sticky like the reference (quirk Q3)
             self._step = max(vol.spacing) * 0.25

@@ -143,8 +143,8 @@ public:
   itkSetMacro(Device, int);
   itkGetMacro(LastDeviceSeconds, double);
   /** Not in the reference: seconds the last GenerateData() spent pouring the flat buffers into the output
-   *  mesh (ITK-lite: one adopted cell array; real ITK: one heap cell per face, as the reference's txx:310-329
-   *  does), and a way around that cost for callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
+   *  mesh (all cells in one slab the mesh carries in its MetaDataDictionary, CellsAllocatedAsStaticArray, where the
+   *  reference's txx:310-329 makes one heap object per face), and a way around that cost for callers that only want the file: the mesh of the last Update(), written as the legacy-ASCII VTK
    *  polydata itk::VTKPolyDataWriter would give for GetOutput(), straight from the device buffers. */
   itkGetMacro(LastMeshFillSeconds, double);
   /** Wall time of the last update's cuberille_extract_host call (upload overlapped with the sweep, then the rest
@@ -189,6 +189,8 @@ private:
   double m_LastExtractSeconds;
   double m_LastDownloadSeconds;
   ::cuberille_ctx    *m_Context;
+  int m_ContextDevice;                        // the device m_Context lives on (SetDevice may come after the constructor)
+  bool AcquireContext(bool mustSucceed);      // create + cuberille_warm_up when there is none (or it sits on another device)
 };
 
 } // end namespace itk

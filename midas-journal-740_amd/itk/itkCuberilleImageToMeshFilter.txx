@@ -6,12 +6,14 @@
 #define __itkCuberilleImageToMeshFilter_txx
 
 #include "itkCuberilleImageToMeshFilter.h"
+#include "itkMetaDataObject.h"
 #include "cuberille_hip.h"
 
 #include <cmath>
 #include <cstdlib>
 #include <ctime>
 #include <new>
+#include <string>
 #include <vector>
 #if __cplusplus >= 201103L
 #include <chrono>
@@ -84,17 +86,62 @@ template <class F> void ParallelRanges(uint64_t n, F f, unsigned int nT = 0)
   f(static_cast<uint64_t>(0), n);
 }
 
-#ifdef ITK_LITE
-template <class TCell> void ReleaseCellSlab(void *slab) { ::operator delete(slab); }   // the shim's cells hold ids only
+// The storage of a mesh's cells when they are made in ONE allocation instead of one `new` per face (txx:309-329 makes
+// 6.3 M heap objects for the bench's sphere).  itk::Mesh offers the mode for it -- CellsAllocatedAsStaticArray: the
+// mesh keeps pointers to cells it does not free (itk::Mesh::ReleaseCellsMemory) -- and the storage is hung into the mesh's
+// own MetaDataDictionary, reference counted: it is released when the mesh is destroyed, or when the next fill of the same
+// mesh replaces it.  So the mesh still carries everything it needs, may be disconnected from the pipeline
+// (Testing/CuberilleTest01.cxx:161-162) and may outlive the filter.  Only ITK API: the same code for ITK and ITK-lite.
+template <class TCell> class CellSlab : public LightObject
+{
+public:
+  typedef CellSlab Self;
+  typedef LightObject Superclass;
+  typedef SmartPointer<Self> Pointer;
+  typedef SmartPointer<const Self> ConstPointer;
+  itkNewMacro(Self);
+  itkTypeMacro(CellSlab, LightObject);
+  // raw storage for n cells; the filling threads construct them in place and say how many exist
+  TCell *Allocate(uint64_t n)
+  {
+    Release();
+    m_Cells = static_cast<TCell *>(::operator new(sizeof(TCell) * static_cast<size_t>(n ? n : 1)));
+    return m_Cells;
+  }
+  void SetNumberOfConstructedCells(uint64_t n) { m_Constructed = n; }
+protected:
+  CellSlab() : m_Cells(0), m_Constructed(0) {}
+  ~CellSlab() { Release(); }
+private:
+  CellSlab(const Self &);
+  void operator=(const Self &);
+  void Release()
+  {
+    for (uint64_t c = 0; c < m_Constructed; c++) m_Cells[c].~TCell();
+    ::operator delete(m_Cells);
+    m_Cells = 0;
+    m_Constructed = 0;
+  }
+  TCell *m_Cells;
+  uint64_t m_Constructed;
+};
 
-// Bulk form of the loop at txx:309-329 for the ITK-lite mesh: the cells of the whole mesh are constructed in ONE
-// array, which the mesh adopts (it owns and frees its cells, as a whole); the cell container holds pointers into it.
+// Bulk form of the loop at txx:309-329: all cells of the mesh constructed in one slab, the cell container filled with
+// pointers into it by a few threads.
 template <class TMesh, class TCell, unsigned int K>
 void BulkFillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells)
 {
   typedef typename TMesh::CellType BaseCellType;
   typedef typename TMesh::PointIdentifier PointIdentifier;
-  TCell *slab = static_cast<TCell *>(::operator new(sizeof(TCell) * (nCells ? nCells : 1)));
+  typedef typename TMesh::CellsContainer CellsContainer;
+  typename CellSlab<TCell>::Pointer holder = CellSlab<TCell>::New();
+  TCell *slab = holder->Allocate(nCells);
+  if (mesh->GetCells() == 0)
+    {
+    typename CellsContainer::Pointer fresh = CellsContainer::New();
+    mesh->SetCells(fresh);
+    }
+  mesh->SetCellsAllocationMethod(TMesh::CellsAllocatedAsStaticArray);
   std::vector<BaseCellType *> &container = mesh->GetCells()->CastToSTLContainer();
   container.resize(static_cast<size_t>(nCells));
   BaseCellType **slots = nCells ? &container[0] : 0;
@@ -114,10 +161,30 @@ void BulkFillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells)
       }
     } fill = {slab, slots, ids};
   ParallelRanges(nCells, fill);
-  mesh->SetCellsAllocationMethod(TMesh::CellsAllocatedAsStaticArray);
-  mesh->AdoptCellArray(slab, &ReleaseCellSlab<TCell>);
+  holder->SetNumberOfConstructedCells(nCells);
+  EncapsulateMetaData<typename CellSlab<TCell>::Pointer>(mesh->GetMetaDataDictionary(), std::string("CuberilleCellSlab"), holder);
 }
-#endif
+
+// the image as the C ABI takes it (itk::Image::{GetBufferedRegion, GetSpacing, GetDirection} and the physical position of
+// the first buffered pixel: txx:71-99,266-270); false when nothing is buffered yet
+template <class TImage> bool DescribeImage(const TImage *image, cuberille_image_desc &desc)
+{
+  desc.pixel_type = PixelCode<typename TImage::PixelType>::Value;
+  if (!image || TImage::ImageDimension != 3) return false;
+  const typename TImage::RegionType region = image->GetBufferedRegion();
+  typename TImage::PointType firstPixel;
+  image->TransformIndexToPhysicalPoint(region.GetIndex(), firstPixel);   // buffered index 0 of the C ABI
+  bool any = true;
+  for (unsigned int i = 0; i < 3; i++)
+    {
+    desc.dims[i] = static_cast<int64_t>(region.GetSize()[i]);
+    desc.spacing[i] = image->GetSpacing()[i];
+    desc.origin[i] = firstPixel[i];
+    for (unsigned int j = 0; j < 3; j++) desc.direction[i * 3 + j] = image->GetDirection()[i][j];
+    if (desc.dims[i] < 1) any = false;
+    }
+  return any;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Host projection for interpolators the kernels do not implement (TInterpolator other than
@@ -322,6 +389,12 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_LastExtractSeconds = 0.0;
   m_LastDownloadSeconds = 0.0;
   m_Context = 0;
+  m_ContextDevice = -1;
+  // The reference's driver constructs the filter, sets its input and only then starts its clock around ONE Update() in a
+  // fresh process (Testing/CuberilleTest01.cxx:144-160): the GPU context, the code objects and the runtime's queues are
+  // therefore set up here, not inside that Update().  Without a usable device this is silent: GenerateData() tries
+  // again and reports.
+  this->AcquireContext(false);
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>
@@ -332,9 +405,36 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::~CuberilleI
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>
+bool CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::AcquireContext(bool mustSucceed)
+{
+  if (m_Context && m_ContextDevice != m_Device)      // SetDevice after the constructor
+    {
+    cuberille_destroy(m_Context);
+    m_Context = 0;
+    }
+  if (!m_Context)
+    {
+    if (cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
+      {
+      m_Context = 0;
+      if (mustSucceed) itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));
+      return false;
+      }
+    m_ContextDevice = m_Device;
+    (void)cuberille_warm_up(m_Context, 0, 0);
+    }
+  return true;
+}
+
+template <class TInputImage, class TOutputMesh, class TInterpolator>
 void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::SetInput(const InputImageType *image)
 {
   this->ProcessObject::SetNthInput(0, const_cast<InputImageType *>(image));
+  // an image that is buffered already (the driver reads it first, test:113-117): size the device workspace for it now
+  cuberille_image_desc desc;
+  if (cuberille_detail::PixelCode<InputPixelType>::Value >= 0 && cuberille_detail::DescribeImage(image, desc) &&
+      this->AcquireContext(false))
+    (void)cuberille_warm_up(m_Context, &desc, 0);
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>
@@ -359,17 +459,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   m_Interpolator->SetInputImage(image);
 
   cuberille_image_desc desc;
-  desc.pixel_type = cuberille_detail::PixelCode<InputPixelType>::Value;
-  const typename InputImageType::RegionType region = image->GetBufferedRegion();
-  typename InputImageType::PointType firstPixel;
-  image->TransformIndexToPhysicalPoint(region.GetIndex(), firstPixel);   // buffered index 0 of the C ABI
-  for (unsigned int i = 0; i < 3; i++)
-    {
-    desc.dims[i] = static_cast<int64_t>(region.GetSize()[i]);
-    desc.spacing[i] = image->GetSpacing()[i];
-    desc.origin[i] = firstPixel[i];
-    for (unsigned int j = 0; j < 3; j++) desc.direction[i * 3 + j] = image->GetDirection()[i][j];
-    }
+  (void)cuberille_detail::DescribeImage(image.GetPointer(), desc);      // (an empty region is the library's to refuse)
 
   cuberille_params prm;
   prm.iso_value = static_cast<double>(m_IsoSurfaceValue);
@@ -390,8 +480,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
     itkExceptionMacro(<< "USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION / USE_GRADIENT_RECURSIVE_GAUSSIAN are only "
                          "offered with the default LinearInterpolateImageFunction");
 
-  if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
-    itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));
+  this->AcquireContext(true);
   cuberille_result res;
   const double extractStart = cuberille_detail::WallSeconds();
   if (cuberille_extract_host(m_Context, &desc, image->GetBufferPointer(), &prm, &res) != CUBERILLE_OK)
@@ -400,17 +489,15 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
 
   m_LastExtractSeconds = cuberille_detail::WallSeconds() - extractStart;
 
-  // flat buffers (uninitialised: every element is written by the download)
+  // the flat buffers, in host memory the context owns and keeps (cuberille_mesh_host): no allocation of ours, no page
+  // fault per 4 KiB of a fresh destination; valid until the next extraction on the context
   const double downloadStart = cuberille_detail::WallSeconds();
-  float *points = static_cast<float *>(std::malloc(sizeof(float) * (res.n_points * 3 + 1)));
-  uint64_t *cells = static_cast<uint64_t *>(std::malloc(sizeof(uint64_t) * (res.n_cells * res.verts_per_cell + 1)));
-  if (!points || !cells) { std::free(points); std::free(cells); itkExceptionMacro(<< "out of host memory for the mesh buffers"); }
-  if (cuberille_mesh_download(m_Context, points, cells) != CUBERILLE_OK)
-    {
-    std::free(points); std::free(cells);
-    itkExceptionMacro(<< "cuberille_mesh_download: " << cuberille_last_error(m_Context));
-    }
+  float *points = 0;
+  uint64_t *cells = 0;
+  if (cuberille_mesh_host(m_Context, &points, &cells) != CUBERILLE_OK)
+    itkExceptionMacro(<< "cuberille_mesh_host: " << cuberille_last_error(m_Context));
   m_LastDownloadSeconds = cuberille_detail::WallSeconds() - downloadStart;
+  struct FreeOnExit { void *p; ~FreeOnExit() { std::free(p); } } ownCells = {0};   // the host walk's triangles, when it makes them
 
   if (hostWalk)
     {
@@ -421,22 +508,13 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
        m_ProjectVertexMaximumNumberOfSteps};
     // on the calling thread unless the user vouched for the interpolator (SetHostWalkThreads); whatever Evaluate()
     // throws leaves through Update() like any other exception of the pipeline
-    try
-      {
-      cuberille_detail::ParallelRanges(res.n_points, walk, m_HostWalkThreads);
-      }
-    catch (...)
-      {
-      std::free(points); std::free(cells);
-      throw;
-      }
+    cuberille_detail::ParallelRanges(res.n_points, walk, m_HostWalkThreads);
     if (m_GenerateTriangleFaces)
       {
-      uint64_t *tri = static_cast<uint64_t *>(std::malloc(sizeof(uint64_t) * (res.n_cells * 6 + 1)));
-      if (!tri) { std::free(points); std::free(cells); itkExceptionMacro(<< "out of host memory for the mesh buffers"); }
-      cuberille_detail::SplitQuads(points, cells, res.n_cells, tri);
-      std::free(cells);
-      cells = tri;
+      ownCells.p = std::malloc(sizeof(uint64_t) * (res.n_cells * 6 + 1));
+      if (!ownCells.p) itkExceptionMacro(<< "out of host memory for the mesh buffers");
+      cuberille_detail::SplitQuads(points, cells, res.n_cells, static_cast<uint64_t *>(ownCells.p));
+      cells = static_cast<uint64_t *>(ownCells.p);
       res.n_cells *= 2;
       res.verts_per_cell = 3;
       }
@@ -455,40 +533,9 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
       } fp = {res.n_points ? &pc[0] : 0, points};
     cuberille_detail::ParallelRanges(res.n_points, fp);
   }
-#ifdef ITK_LITE
-  // ITK-lite mesh: all cells in one array that the mesh adopts and frees as a whole
+  // all cells in one slab that lives and dies with the mesh (CellSlab above); the mesh holds pointers into it
   if (res.verts_per_cell == 3) cuberille_detail::BulkFillCells<OutputMeshType, TriangleCellType, 3>(mesh.GetPointer(), cells, res.n_cells);
   else cuberille_detail::BulkFillCells<OutputMeshType, QuadrilateralCellType, 4>(mesh.GetPointer(), cells, res.n_cells);
-#else
-  // real ITK: one heap cell per face handed to the mesh, which owns it from then on, exactly as the reference
-  // does (txx:309-329) -- itk::Mesh frees CellsAllocatedDynamicallyCellByCell cells one by one
-  if (res.verts_per_cell == 3)
-    {
-    PointIdentifier ids[3];
-    for (uint64_t c = 0; c < res.n_cells; c++)
-      {
-      for (int k = 0; k < 3; k++) ids[k] = static_cast<PointIdentifier>(cells[3 * c + k]);
-      TriangleCellAutoPointer cell;
-      cell.TakeOwnership(new TriangleCellType);
-      cell->SetPointIds(ids);
-      mesh->SetCell(static_cast<CellIdentifier>(c), cell);
-      }
-    }
-  else
-    {
-    PointIdentifier ids[4];
-    for (uint64_t c = 0; c < res.n_cells; c++)
-      {
-      for (int k = 0; k < 4; k++) ids[k] = static_cast<PointIdentifier>(cells[4 * c + k]);
-      QuadrilateralCellAutoPointer cell;
-      cell.TakeOwnership(new QuadrilateralCellType);
-      cell->SetPointIds(ids);
-      mesh->SetCell(static_cast<CellIdentifier>(c), cell);
-      }
-    }
-#endif
-  std::free(points);
-  std::free(cells);
   m_LastMeshFillSeconds = cuberille_detail::WallSeconds() - fillStart;
 }
 
@@ -503,8 +550,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::WriteL
 template <class TInputImage, class TOutputMesh, class TInterpolator>
 double CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::MeasureHostToDeviceSeconds(unsigned long long bytes)
 {
-  if (!m_Context && cuberille_create(&m_Context, m_Device) != CUBERILLE_OK)
-    itkExceptionMacro(<< "cuberille_create: " << cuberille_last_error(0));
+  this->AcquireContext(true);
   double s = 0.0;
   if (cuberille_debug_h2d_seconds(m_Context, static_cast<size_t>(bytes), &s) != CUBERILLE_OK)
     itkExceptionMacro(<< "cuberille_debug_h2d_seconds: " << cuberille_last_error(m_Context));

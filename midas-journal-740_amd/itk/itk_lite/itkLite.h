@@ -153,15 +153,67 @@ protected:
   mutable int m_Ref;
 };
 
+// itk::MetaDataDictionary / MetaDataObject<T> / EncapsulateMetaData / ExposeMetaData (itkMetaDataObject.h): string-keyed,
+// reference-counted values that live and die with the itk::Object that carries them
+class MetaDataObjectBase : public LightObject {
+public:
+  typedef MetaDataObjectBase Self;
+  typedef SmartPointer<Self> Pointer;
+  virtual const char *GetNameOfClass() const { return "MetaDataObjectBase"; }
+protected:
+  MetaDataObjectBase() {}
+};
+template <class T> class MetaDataObject : public MetaDataObjectBase {
+public:
+  typedef MetaDataObject Self;
+  typedef SmartPointer<Self> Pointer;
+  static Pointer New() { Pointer p = new Self; return p; }
+  virtual const char *GetNameOfClass() const { return "MetaDataObject"; }
+  void SetMetaDataObjectValue(const T &v) { m_Value = v; }
+  const T &GetMetaDataObjectValue() const { return m_Value; }
+protected:
+  MetaDataObject() : m_Value() {}
+  T m_Value;
+};
+class MetaDataDictionary {
+public:
+  MetaDataObjectBase::Pointer &operator[](const std::string &key) { return m_Map[key]; }
+  bool HasKey(const std::string &key) const { return m_Map.find(key) != m_Map.end(); }
+  const MetaDataObjectBase *Get(const std::string &key) const {
+    std::map<std::string, MetaDataObjectBase::Pointer>::const_iterator it = m_Map.find(key);
+    return it == m_Map.end() ? 0 : it->second.GetPointer();
+  }
+  bool Erase(const std::string &key) { return m_Map.erase(key) != 0; }
+private:
+  std::map<std::string, MetaDataObjectBase::Pointer> m_Map;
+};
+template <class T> inline void EncapsulateMetaData(MetaDataDictionary &dict, const std::string &key, const T &value) {
+  typename MetaDataObject<T>::Pointer o = MetaDataObject<T>::New();
+  o->SetMetaDataObjectValue(value);
+  dict[key] = o.GetPointer();
+}
+template <class T> inline bool ExposeMetaData(const MetaDataDictionary &dict, const std::string &key, T &out) {
+  const MetaDataObject<T> *o = dynamic_cast<const MetaDataObject<T> *>(dict.Get(key));
+  if (!o) return false;
+  out = o->GetMetaDataObjectValue();
+  return true;
+}
+
 class Object : public LightObject {
 public:
   typedef Object Self;
   virtual const char *GetNameOfClass() const { return "Object"; }
   virtual void Modified() const { ++m_MTime; }
   unsigned long GetMTime() const { return m_MTime; }
+  MetaDataDictionary &GetMetaDataDictionary() { if (!m_Dictionary) m_Dictionary = new MetaDataDictionary; return *m_Dictionary; }
 protected:
-  Object() : m_MTime(1) {}
+  Object() : m_MTime(1), m_Dictionary(0) {}
+  ~Object() { delete m_Dictionary; }          // after the derived classes' destructors: what the dictionary holds goes last
   mutable unsigned long m_MTime;
+  MetaDataDictionary *m_Dictionary;
+private:
+  Object(const Object &);
+  void operator=(const Object &);
 };
 
 #define itkNewMacro(x)                                  \
@@ -514,24 +566,21 @@ public:
   unsigned long GetNumberOfCells() const { return m_Cells.IsNull() ? 0 : m_Cells->Size(); }
   void SetPoint(PointIdentifier id, const PointType &p) { GetPoints()->InsertElement(id, p); }
   bool GetPoint(PointIdentifier id, PointType *p) const { if (m_Points.IsNull() || id >= m_Points->Size()) return false; *p = m_Points->GetElement(id); return true; }
-  // How the cell objects were allocated, hence who frees them (names and meaning of itk::Mesh):
+  void SetCells(CellsContainer *cells) { if (m_Cells.GetPointer() != cells) { ReleaseCellsMemory(); m_Cells = cells; this->Modified(); } }
+  // How the cell objects were allocated, hence who frees them (names and meaning of itk::Mesh::ReleaseCellsMemory):
   //   CellsAllocatedDynamicallyCellByCell  each cell came from its own `new` and the mesh deletes it (txx:310-313);
-  //   CellsAllocatedAsStaticArray          the cells live in storage the mesh does not free cell by cell.
-  // ITK-lite addition: AdoptCellArray hands such an array TO the mesh, which releases it as a whole (one call) when it
-  // is re-initialised or destroyed -- the bulk fill of the MI355X filter uses it, so the mesh still owns its cells.
+  //   CellsAllocatedAsStaticArray          the cells live in storage that is not the mesh's to free: it only forgets the
+  //                                        pointers.  (The MI355X filter's bulk fill keeps that storage in an object it
+  //                                        hangs into the mesh's MetaDataDictionary, so it still lives and dies with the mesh.)
+  //   CellsAllocatedAsADynamicArray        one `new[]` whose first cell is the array: the mesh delete[]s it.
   enum CellsAllocationMethodType { CellsAllocationMethodUndefined, CellsAllocatedAsStaticArray,
                                    CellsAllocatedAsADynamicArray, CellsAllocatedDynamicallyCellByCell };
   void SetCellsAllocationMethod(CellsAllocationMethodType m) { m_CellsAllocationMethod = m; }
   CellsAllocationMethodType GetCellsAllocationMethod() const { return m_CellsAllocationMethod; }
-  void AdoptCellArray(void *array, void (*release)(void *)) {
-    ReleaseCellArray();
-    m_CellArray = array;
-    m_ReleaseCellArray = release;
-  }
   // the mesh takes over the cell object and deletes it later (ITK ownership rule, txx:310-313)
   void SetCell(CellIdentifier id, CellAutoPointer &cell) {
     CellsContainer *c = GetCells();
-    if (m_CellsAllocationMethod != CellsAllocatedAsStaticArray && id < c->Size() && c->ElementAt(id)) delete c->ElementAt(id);
+    if (m_CellsAllocationMethod == CellsAllocatedDynamicallyCellByCell && id < c->Size() && c->ElementAt(id)) delete c->ElementAt(id);
     c->InsertElement(id, cell.ReleaseOwnership());
   }
   bool GetCell(CellIdentifier id, CellAutoPointer &cell) const {
@@ -540,28 +589,24 @@ public:
     return true;
   }
   virtual void Initialize() {
-    if (m_Cells.IsNotNull()) {
-      if (m_CellsAllocationMethod != CellsAllocatedAsStaticArray)
-        for (CellIdentifier i = 0; i < m_Cells->Size(); i++) delete m_Cells->ElementAt(i);
-      m_Cells->Initialize();
-    }
-    ReleaseCellArray();
+    ReleaseCellsMemory();
     m_CellsAllocationMethod = CellsAllocatedDynamicallyCellByCell;
     if (m_Points.IsNotNull()) m_Points->Initialize();
   }
 protected:
-  Mesh() : m_CellsAllocationMethod(CellsAllocatedDynamicallyCellByCell), m_CellArray(0), m_ReleaseCellArray(0) {}
-  ~Mesh() { Initialize(); }
-  void ReleaseCellArray() {
-    if (m_CellArray && m_ReleaseCellArray) m_ReleaseCellArray(m_CellArray);
-    m_CellArray = 0;
-    m_ReleaseCellArray = 0;
+  Mesh() : m_CellsAllocationMethod(CellsAllocatedDynamicallyCellByCell) {}
+  ~Mesh() { ReleaseCellsMemory(); }
+  void ReleaseCellsMemory() {
+    if (m_Cells.IsNull()) return;
+    if (m_CellsAllocationMethod == CellsAllocatedDynamicallyCellByCell)
+      for (CellIdentifier i = 0; i < m_Cells->Size(); i++) delete m_Cells->ElementAt(i);
+    else if (m_CellsAllocationMethod == CellsAllocatedAsADynamicArray && m_Cells->Size())
+      delete[] m_Cells->ElementAt(0);
+    m_Cells->Initialize();
   }
   PointsContainerPointer m_Points;
   CellsContainerPointer m_Cells;
   CellsAllocationMethodType m_CellsAllocationMethod;
-  void *m_CellArray;
-  void (*m_ReleaseCellArray)(void *);
 };
 
 // declared so that the driver's typedefs and includes resolve; never instantiated

@@ -2081,3 +2081,36 @@ def test_slice_counts_add_up(pkg, oracle, extractor, volumes):
     extractor.emit(0)
     with pytest.raises(pkg._abi.CuberilleError):
         extractor.slice_counts(b - a + 1)
+
+
+def test_warm_up_and_host_mesh(pkg, oracle, volumes):
+    """cuberille_warm_up (what the drop-in filter calls from its constructor and from SetInput, so that the one cold
+    Update() the reference's driver times -- test:158-160 -- does not pay for the context) leaves no trace in the results:
+    the first extraction after it equals the oracle; cuberille_mesh_host hands out the context's own host copy of the
+    mesh, the same bytes as cuberille_mesh_download, the same pointers when asked twice, refreshed by the next extraction."""
+    ex = pkg.Extractor(0)
+    try:
+        vol = volumes("nucleon.mha")
+        desc = pkg.make_desc(np.uint8, vol.dims)
+        ex.warm_up()                       # code objects only
+        ex.warm_up(desc)                   # + the workspace for this image
+        kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+        for name, iso in (("nucleon.mha", 140), ("fuel.mha", 15), ("nucleon.mha", 140)):
+            v = volumes(name)
+            ex.extract_host(v, pkg.make_params(iso, **kw))
+            ref = oracle.run(v.voxels, iso, **kw)
+            view = ex.mesh_host()
+            assert_same_mesh(view, ref)
+            again = ex.mesh_host()
+            assert again.points.ctypes.data == view.points.ctypes.data and again.cells.ctypes.data == view.cells.ctypes.data
+            assert_same_mesh(ex.download(), ref)
+        ex.warm_up(pkg.make_desc(np.float32, (64, 64, 64)))        # between extractions: only reserves
+        assert_same_mesh(ex.mesh_host(), ref)
+    finally:
+        ex.close()
+    # the Python mirror of the filter warms up the same way (constructor, SetInput) and gives the oracle's mesh
+    f = pkg.CuberilleImageToMeshFilter(device=0)
+    f.SetInput(volumes("fuel.mha"))
+    f.SetIsoSurfaceValue(128)
+    f.Update()
+    assert_same_mesh(f.GetOutput(), oracle.run(volumes("fuel.mha").voxels, 128))
