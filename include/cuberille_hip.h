@@ -101,7 +101,8 @@ enum { CUBERILLE_PROJECT_DEFAULT = 0, CUBERILLE_PROJECT_ADVANCED = 1, CUBERILLE_
 enum { CUBERILLE_GRADIENT_CENTRAL = 0, CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN = 1 };
 
 /* Z-slab placement for multi-GPU runs (one process per GPU).
- * NULL or all-zero means "the buffer is the whole volume". */
+ * NULL or all-zero ranges mean "the buffer is the whole volume" (the two events are honoured either way: a caller that
+ * filled the volume on another stream passes only voxels_ready_event). */
 typedef struct {
   int64_t global_nz;        /* Nz of the whole volume */
   int64_t z_begin;          /* global z of the buffer's first slice */

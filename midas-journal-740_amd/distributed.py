@@ -364,13 +364,19 @@ class ShardedExtractor:
         from .cuberille import required_halo
         self.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
         if self.world == 1:
-            if buf.is_cuda:
-                torch.cuda.current_stream().synchronize()
             # (cuberille_extract_device is the one-wait step with a single rank: from the second extraction on a context
-            #  on, everything is launched back to back and the host waits once)
-            res = self.ex.extract_device(buf.data_ptr(), self.desc, params, None)
+            #  on, everything is launched back to back and the host waits once.  The library runs on a stream of its own:
+            #  an event recorded behind whatever wrote the buffer on torch's current stream orders it -- no host wait)
+            slab = None
+            if buf.is_cuda:
+                from . import _abi
+                if self._vox_event is None:
+                    self._vox_event = torch.cuda.Event()
+                self._vox_event.record(torch.cuda.current_stream())
+                slab = _abi.Slab(0, 0, 0, 0, 0, 0, None, self._vox_event.cuda_event)    # all-zero ranges: the whole volume
+            res = self.ex.extract_device(buf.data_ptr(), self.desc, params, slab)
             self.counts = np.array([[int(res.n_points), int(res.n_cells)]], dtype=np.int64)
-            self.stats["host_syncs"] = 2 if buf.is_cuda else 0
+            self.stats["host_syncs"] = 1 if buf.is_cuda else 0
             return res
         need = max(required_halo(self.desc, params))
         if need > self.halo:
