@@ -986,8 +986,11 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
   if (c->stepMode != 1) {
     // sized by a host read (the first extraction on a context, a fallback configuration): the vertex phase unless a
     // quirk-Q1 flag says that the counts may still change
+    // (a source slice in this slab's own halo -- aliasMustResolve -- means a recount for certain; "nothing in my buffer
+    //  below my first occupied slice" is an assumption the count has made already and the rows of the ranks below usually
+    //  confirm: the vertex phase runs on it, the cell pass decides from the rows -- row_flags)
     c->stepMode = 2;
-    if (!c->aliasBelowBuffer) {
+    if (!c->aliasMustResolve) {
       rc = emit_points_phase(c);
       if (rc) return rc;
     }
@@ -1037,7 +1040,7 @@ int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank,
   u32 flags = 0;
   u64 off = base;
   for (int r = 0; r < n_ranks; r++) {
-    flags |= c->hostRows[r].err;
+    flags |= row_flags(c->hostRows, r);                      // (the rule the cell pass applied on the device)
     if (r < rank) off += c->hostRows[r].totV - c->hostRows[r].V0;
   }
   const u32 mine = c->hostTotals->err;
@@ -1077,6 +1080,7 @@ int cuberille_failed_row(void *host_row, size_t capacity, size_t *row_bytes) {
   if (row_bytes) *row_bytes = sizeof(Totals);
   if (!host_row || capacity < sizeof(Totals)) return CUBERILLE_ERR_ARGUMENT;
   Totals t{};
+  t.aliasZ = t.topZ = t.top2Z = -1;
   t.err = ERRF_RANK_FAILED;        // counts of zero: the ranks above add nothing to their offsets, and write nothing anyway
   std::memcpy(host_row, &t, sizeof t);
   return CUBERILLE_OK;

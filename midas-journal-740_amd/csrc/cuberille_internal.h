@@ -53,6 +53,11 @@ struct Totals {        // device-resident, zeroed before every count, mirrored t
                        // or more than it holds: ERRF_ESCAPE_OVERFLOW)
   u32 go;              // cuberille_step_begin: 1 when the kernels launched blindly behind the count may run (k_gate)
   u64 stopThr, stopSteps;   // walks of owned vertices that ended within the threshold / out of steps (txx:457-459, 470-472)
+  // what the ranks need of each other to judge an ERRF_ALIAS_BELOW_BUFFER without the host (row_flags; global slices,
+  // -1: none; written by k_block_scan): the first occupied slice of the counted range -- the one such a flag is about --
+  // and the highest and second-highest occupied OWNED slices (cuberille_slab_status has the same three for the host)
+  int aliasZ, topZ, top2Z;
+  u32 reserved;
 };
 
 enum {
@@ -64,6 +69,25 @@ enum {
   ERRF_RANK_FAILED = 32          // never raised by a kernel: the row a driver contributes for a rank whose
                                  // cuberille_step_begin failed (cuberille_failed_row)
 };
+
+// The flags of rank r's row as the step sees them (k_emit_cells on the device, cuberille_step_end on the host: every
+// rank decides alike from the same gathered rows).  ERRF_ALIAS_BELOW_BUFFER says "my first occupied slice, aliasZ, has only
+// empty slices below it in my buffer: I counted as if nothing were occupied further down" -- which is TRUE, and no flag at
+// all, unless some rank below owns an occupied slice strictly below aliasZ (the rule of the driver's alias_plan: a rank's
+// highest occupied slice, or its second highest when the highest IS aliasZ -- the ghost slice of the rank above).
+__host__ __device__ inline u32 row_flags(const Totals *rows, int r) {
+  u32 e = rows[r].err;
+  if (e & (u32)ERRF_ALIAS_BELOW_BUFFER) {
+    const int az = rows[r].aliasZ;
+    bool source = az < 0;                    // (a row that does not say what the flag is about: leave it standing)
+    for (int s = 0; s < r; s++) {
+      const int h = rows[s].topZ < az ? rows[s].topZ : rows[s].top2Z;
+      if (h >= 0 && h < az) source = true;
+    }
+    if (!source) e &= ~(u32)ERRF_ALIAS_BELOW_BUFFER;
+  }
+  return e;
+}
 
 // A count block owns COUNT_WB consecutive words of the flat raster order = 32 scan segments of 64 words.
 // Absolute exclusive prefix of word gi = blockBase[gi >> COUNT_LG] + segPre[gi >> 6] + prefix[gi].

@@ -861,10 +861,31 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
 // gate (cuberille_step_begin): the launches behind this one were sized from the previous extraction; they only run
 // (Totals::go) when the counts fit what they were sized for and no flag of the count stands.
 __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blockTot, u64 *__restrict__ blockBase, u32 nblk,
-                                                     size_t g0, Totals *__restrict__ tot, Gate gate) {
+                                                     size_t g0, Totals *__restrict__ tot, Gate gate,
+                                                     const u32 *__restrict__ sliceOcc, int cz0, int oz0, int oz1, long long zglob0) {
   constexpr int ROWS = 8;
   __shared__ u64 waveSum[16];
+  __shared__ int firstOcc, topOcc, top2Occ;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the three slices of the row (row_flags): first occupied slice of the counted range, highest and second-highest
+  // occupied owned slice
+  if (tid == 0) { firstOcc = 0x7fffffff; topOcc = -1; top2Occ = -1; }
+  __syncthreads();
+  for (int z = cz0 + tid; z < oz1; z += 1024)
+    if (sliceOcc[z]) {
+      atomicMin(&firstOcc, z);
+      if (z >= oz0) atomicMax(&topOcc, z);
+    }
+  __syncthreads();
+  const int top = topOcc;
+  for (int z = oz0 + tid; z < top; z += 1024)
+    if (sliceOcc[z]) atomicMax(&top2Occ, z);
+  __syncthreads();
+  if (tid == 0) {
+    tot->aliasZ = firstOcc == 0x7fffffff ? -1 : (int)(zglob0 + firstOcc);
+    tot->topZ = top < 0 ? -1 : (int)(zglob0 + top);
+    tot->top2Z = top2Occ < 0 ? -1 : (int)(zglob0 + top2Occ);
+  }
   u64 runV = 0, runQ = 0;
   for (u32 base = 0; base < nblk; base += 1024 * ROWS) {
     u64 v[ROWS];
@@ -906,7 +927,10 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
       u32 err = tot->err;
       if (runV > gate.coverV || runQ > gate.coverQ || tot->nVertexWords > gate.coverVW) err |= (u32)ERRF_CAPACITY;
       tot->err = err;
-      tot->go = (err & (u32)(ERRF_ALIAS_UNKNOWN | ERRF_ALIAS_BELOW_BUFFER | ERRF_CAPACITY)) == 0 ? 1u : 0u;
+      // (ERRF_ALIAS_BELOW_BUFFER alone does not close the gate: the count assumed that nothing is occupied below this
+      //  buffer, which is what the rows of the ranks below usually confirm -- the vertex phase runs on that assumption and
+      //  the cell pass, which sees all rows, decides; a recount voids it when the assumption was wrong)
+      tot->go = (err & (u32)(ERRF_ALIAS_UNKNOWN | ERRF_CAPACITY)) == 0 ? 1u : 0u;
     }
   }
 }
@@ -1416,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
     u32 flags = 0;
     u64 off = 0;
     for (int r = 0; r < a.nRanks; r++) {
-      flags |= a.rows[r].err;
+      flags |= row_flags(a.rows, r);
       if (r < a.rank) off += a.rows[r].totV - a.rows[r].V0;
     }
     if (flags) return;
@@ -2338,7 +2362,7 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals, 0);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
-  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate);
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0);
   return hipGetLastError();
 }
 

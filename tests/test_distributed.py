@@ -266,15 +266,16 @@ def _fake_worker(rank, world, port, scenario, out_dir):
                                      slice_bits_device=slice_bits_device, recount=recount, escaped_count=escaped_count,
                                      reproject_escaped=reproject_escaped)
         if scenario.startswith("step"):
-            # the one-wait step (cuberille_step_begin / _end) with a stand-in: the row is the library's -- ten 64-bit words,
+            # the one-wait step (cuberille_step_begin / _end) with a stand-in: the row is the library's -- 64-bit words,
             # counts first, the flags in the low half of word 6 -- in host memory here
             import ctypes
+            NW = pkg._abi.failed_row().nbytes // 8         # words of a row (the library's: opaque to the driver)
 
             def step_begin(ptr, desc, params, slab):
                 calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
                 if scenario == "step_begin_fails" and rank == 1:
                     raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic step_begin failure")
-                row = np.zeros(10, dtype=np.int64)
+                row = np.zeros(NW, dtype=np.int64)
                 row[0], row[1] = 100 + rank, 7 * (rank + 1)
                 calls["row"] = row
                 return row.ctypes.data, row.nbytes
@@ -282,7 +283,7 @@ def _fake_worker(rank, world, port, scenario, out_dir):
             def step_end(rows_ptr, n_ranks, r):
                 if scenario == "step_end_fails" and rank == 0:
                     raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic step_end failure")
-                rows = np.frombuffer((ctypes.c_int64 * (10 * n_ranks)).from_address(rows_ptr), dtype=np.int64).reshape(n_ranks, 10)
+                rows = np.frombuffer((ctypes.c_int64 * (NW * n_ranks)).from_address(rows_ptr), dtype=np.int64).reshape(n_ranks, NW)
                 res = types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
                 if (rows[:, 6] & 0xffffffff).any():
                     calls["retry"] = True

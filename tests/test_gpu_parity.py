@@ -1167,11 +1167,25 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
         sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.from_numpy(vox[:1]).dtype, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vox[sh.z0:sh.z1]).cuda()      # owned slices only
-        sh.extract(buf, prm)
+        first = sh.extract(buf, prm)
         whole = sh.gather_mesh(dst=0, on_device=False)
         if whole is not None:
             np.save(os.path.join(out_dir, "gp.npy"), whole.points)
             np.save(os.path.join(out_dir, "gc.npy"), whole.cells)
+        # two more steps on the same contexts: launched blindly from the sizes of the one before (the halo slices wiped, so
+        # that the exchange has to bring them again) -- the same mesh, and what the step cost besides kernels
+        stats = [dict(sh.stats)]
+        for _ in range(2):
+            buf[:sh.z0 - sh.lo].zero_()
+            buf[sh.z1 - sh.lo:].zero_()
+            again = sh.extract(buf, prm)
+            assert (int(again.n_points), int(again.n_cells)) == (int(first.n_points), int(first.n_cells))
+            stats.append(dict(sh.stats))
+        whole = sh.gather_mesh(dst=0, on_device=False)
+        if whole is not None:
+            np.save(os.path.join(out_dir, "gp2.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc2.npy"), whole.cells)
+        np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([repr(stats)]))
         ex.close()
     finally:
         dist.destroy_process_group()
@@ -1179,7 +1193,7 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
 
 @pytest.mark.parametrize("case", ["two_voxels_empty_rank_between", "source_in_the_halo", "source_in_the_halo_no_corner_map",
                                   "marschner_lobb_stacked", "ghost_lowest_occupied", "ghost_source_in_the_halo",
-                                  "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source"])
+                                  "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source", "nothing_occupied_below"])
 def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case):
     """Quirk Q1 (txx:139-141 before 156-161) when the run of empty slices contains a slab boundary: the rank above
     re-uses vertices the rank below created.  Real processes over gloo on this box's GPU: the source slice's inside
@@ -1194,6 +1208,15 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         vox[10, 4, 3] = 255
         vox[40, 3, 3] = 255
         iso, world = 128, 3
+    elif case == "nothing_occupied_below":
+        # rank 1's first occupied slice (40) has only empty slices below it in its buffer (from 24 on) and rank 0 holds
+        # nothing at all: the count raises its "source below my buffer?" flag, the rows of the ranks below answer it on the
+        # device -- no rank owns an occupied slice -- and the step stays a one-wait step (round-3 advisor finding: every
+        # such step used to come back with CUBERILLE_RETRY and take the synchronous protocol on top)
+        rng = np.random.default_rng(5)
+        vox = np.zeros((64, 12, 70), dtype=np.uint8)
+        vox[40:50] = (rng.random((10, 12, 70)) < 0.3) * 255
+        iso, world = 128, 2
     elif case.startswith("source_in_the_halo"):
         rng = np.random.default_rng(3)
         vox = np.zeros((40, 12, 70), dtype=np.uint8)        # cut at 20; slices 16..21 empty, source slice 15 in the halo
@@ -1230,7 +1253,7 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         kw["threshold"] = 0.002
     ref = oracle.run(vox, iso, **kw)
     closed_pts, _ = oracle.closed_form_counts(vox, iso)
-    assert (len(ref.points) < closed_pts) == (case != "ghost_lowest_occupied")    # the reference really re-uses vertices
+    assert (len(ref.points) < closed_pts) == (case not in ("ghost_lowest_occupied", "nothing_occupied_below"))    # the reference really re-uses vertices
     np.save(str(tmp_path / "vol.npy"), vox)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -1244,6 +1267,21 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
     m = M()
     m.points, m.cells = np.load(str(tmp_path / "gp.npy")), np.load(str(tmp_path / "gc.npy"))
     assert_same_mesh(m, ref)
+    m.points, m.cells = np.load(str(tmp_path / "gp2.npy")), np.load(str(tmp_path / "gc2.npy"))     # after the blind steps
+    assert_same_mesh(m, ref)
+    stats = [eval(str(np.load(str(tmp_path / ("stats%d.npy" % r)))[0])) for r in range(world)]
+    if case == "nothing_occupied_below":
+        # every step one collective (the row all-gather), the blind ones with the rehearsal's two host waits (gloo stages
+        # the rows through the host; RCCL: one)
+        assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank), stats
+        assert all(st["host_syncs"] <= 3 for per_rank in stats for st in per_rank[1:]), stats
+    elif case == "ghost_lowest_occupied":
+        # the aliased slice is the lowest occupied slice of the volume: no source, nothing to hand over -- decided from the
+        # rows on the device since the second-highest occupied slices ride in them
+        assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank[1:]), stats
+    elif case in ("two_voxels_empty_rank_between", "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source"):
+        # a real hand-over: the synchronous protocol with its gathers, every step
+        assert all(st["collectives"] >= 2 for per_rank in stats for st in per_rank), stats
 
 
 # ---- the reference's two compiled-out projection branches (h:22-23; txx:340-397, 398-437) -----------------------------
