@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--full-halo", action="store_true", help="N>1: exchange the whole projection-reach halo every step")
     ap.add_argument("--host-offsets", action="store_true",
                     help="N>1: the count all-gather through the host (two more host waits per step) instead of device-resident rows")
+    ap.add_argument("--voxels-first", action="store_true",
+                    help="N>1: the count waits for the halo's VOXELS (round 3) instead of for their bit planes alone (the default: "
+                         "planes right behind the owned sweep, on a communicator of their own; only the walk waits for the voxels)")
     ap.add_argument("--opt", action="append", default=[],
                     help="development: name=value for cuberille_debug_set_option (kernel variants; results never depend on them)")
     ap.add_argument("--partition", default="balanced", choices=["balanced", "uniform"],
@@ -262,7 +265,7 @@ def main():
     prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
                           max_steps=50)
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
-                          device_offsets=not args.host_offsets)
+                          device_offsets=not args.host_offsets, bits_first=not args.voxels_first and not args.host_offsets)
     ex.warm_up(sh.desc)             # code objects, workspace and staging ring for this rank's buffer: before any step
     period = None if strong else n
     if args.workload == "sphere" and not strong:
@@ -293,7 +296,8 @@ def main():
         bounds = balanced_bounds(sh.slice_work(res), world)
         del buf
         sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
-                              device_offsets=not args.host_offsets, bounds=bounds)
+                              device_offsets=not args.host_offsets, bounds=bounds,
+                              bits_first=not args.voxels_first and not args.host_offsets)
         buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
         buf[:sh.z0 - sh.lo].zero_()
         buf[sh.z1 - sh.lo:].zero_()
@@ -305,7 +309,7 @@ def main():
     # the timed region carries the two event pairs every extraction has (the pass over the volume, the emit phase);
     # the per-stage events cost the stream about 8 us each and are switched on for a few extra extractions afterwards
     live = {"ms_pass": 0.0, "ms_total": 0.0}
-    host_side = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": 0}
+    host_side = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": 0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -413,6 +417,8 @@ def main():
         }
         # what a step costs besides kernels (rank 0's view; per step, averaged over the timed region)
         out["host_side"] = {"halo_bytes_per_rank": host_side["halo_bytes"] // args.steps,
+                            "halo_bit_plane_bytes_per_rank": host_side["halo_bit_bytes"] // args.steps,
+                            "halo_order": "bit planes first (count), voxels for the walk" if sh.bits_first else "voxels",
                             "host_syncs_per_step": round(host_side["host_syncs"] / args.steps, 2),
                             "collectives_per_step": round(host_side["collectives"] / args.steps, 2),
                             "escaped_walks_per_step": round(host_side["escaped"] / args.steps, 2),

@@ -239,6 +239,22 @@ int cuberille_emit(cuberille_ctx *ctx, uint64_t point_id_offset, cuberille_resul
 int cuberille_step_begin(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
                          const cuberille_params *prm, const cuberille_slab *slab, const void **dev_row, size_t *row_bytes);
 int cuberille_step_end(cuberille_ctx *ctx, const void *dev_rows, int n_ranks, int rank, cuberille_result *res);
+/* cuberille_step_begin in two calls, for a driver that sends the neighbour ranks the inside BITS of its boundary slices ahead
+ * of their voxels: everything between the sweep and the walk -- faces, vertex ids, prefix sums, the vertex scatter -- reads
+ * the 1-bit volume alone (1/32 of the bytes of a float32 slice: microseconds on a link), only the projection walk reads the
+ * halo's voxels.  cuberille_step_classify (arguments of cuberille_count; halo_ready_event of the slab is ignored) thresholds
+ * the OWNED slices and returns at once; *dev_bits is the bit volume of the buffer, slice z (local) at dev_bits + z *
+ * words_per_slice, (Nx+63)/64 words per x-row -- complete for the owned slices when the context's stream gets there.  The
+ * driver sends its neighbours the planes of the owned slices they hold as halo and receives, INTO dev_bits, the planes of its
+ * own halo slices (every slice of the buffer outside [own_z0, own_z1): they are never thresholded here).
+ * cuberille_step_count(halo_bits_event, halo_voxels_event, ...) then continues as cuberille_step_begin does behind its sweep:
+ * the count waits for halo_bits_event (recorded by the caller behind the arrival of the planes; null: they are there
+ * already), the walk -- alone -- for halo_voxels_event (recorded behind the arrival of the halo's voxels; null likewise).
+ * Same row, same cuberille_step_end, same results bit for bit: the planes a neighbour sends are the bits this rank would
+ * have computed from the same voxels. */
+int cuberille_step_classify(cuberille_ctx *ctx, const cuberille_image_desc *img, const void *dev_voxels,
+                            const cuberille_params *prm, const cuberille_slab *slab, uint64_t **dev_bits, size_t *words_per_slice);
+int cuberille_step_count(cuberille_ctx *ctx, void *halo_bits_event, void *halo_voxels_event, const void **dev_row, size_t *row_bytes);
 /* A rank whose cuberille_step_begin FAILED has no row, yet its peers are on their way into the all-gather of the rows:
  * this writes, into `capacity` bytes of HOST memory, a row that says "this rank failed" (*row_bytes: its size, the same
  * as every row's).  The driver copies it to the device and contributes it to the gather in place of the row it does not

@@ -26,7 +26,7 @@ EXPORTS = [
     "cuberille_required_halo", "cuberille_slab_info", "cuberille_debug_set_option", "cuberille_debug_h2d_seconds",
     "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
     "cuberille_minimum_halo", "cuberille_escaped_count", "cuberille_reproject_escaped", "cuberille_step_begin", "cuberille_step_end",
-    "cuberille_slice_counts", "cuberille_failed_row", "cuberille_warm_up", "cuberille_mesh_host",
+    "cuberille_slice_counts", "cuberille_failed_row", "cuberille_warm_up", "cuberille_mesh_host", "cuberille_step_classify", "cuberille_step_count",
 ]
 ABI_VERSION = 10
 
@@ -134,6 +134,9 @@ def lib():
     L.cuberille_reproject_escaped.argtypes = [vp, vp, C.c_int64, C.c_int64]
     L.cuberille_step_begin.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), C.POINTER(vp),
                                        C.POINTER(C.c_size_t)]
+    L.cuberille_step_classify.argtypes = [vp, C.POINTER(ImageDesc), vp, C.POINTER(Params), C.POINTER(Slab), C.POINTER(vp),
+                                          C.POINTER(C.c_size_t)]
+    L.cuberille_step_count.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cuberille_step_end.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(Result)]
     L.cuberille_slice_counts.argtypes = [vp, vp, vp, C.c_size_t]
     L.cuberille_warm_up.argtypes = [vp, C.POINTER(ImageDesc), C.POINTER(Params)]

@@ -111,7 +111,10 @@ struct cuberille_ctx {
   u32 histVW = 0;
   bool histDense = false;                // ... and whether a quarter or more of its words created vertices
   bool histShortWalks = false;           // ... and whether its walks took fewer than four passes per vertex on average
-  int stepMode = 0;                      // 0: no step open; 1: launched blindly (sizes on the device); 2: sized by a host read
+  int stepMode = 0;                      // 0: no step open; 1: launched blindly (sizes on the device); 2: sized by a host read;
+                                         // 3: cuberille_step_classify has run, cuberille_step_count is next
+  hipEvent_t voxelHaloEvent = nullptr;   // cuberille_step_count: the halo's VOXELS are complete behind this event of the
+                                         // caller's (only the walk reads them; everything before it needs their bits alone)
   Totals *hostRows = nullptr;            // pinned: the gathered totals of all ranks, read back by cuberille_step_end
   size_t hostRowsCap = 0;
   u64 pointOffset = 0;                   // of the last emit
@@ -397,6 +400,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   c->haveMesh = false;
   c->hostMeshValid = false;
   c->stepMode = 0;
+  c->voxelHaloEvent = nullptr;
   c->aliasBelowBuffer = false;
   c->aliasMustResolve = false;
   c->aliasZ = -1;
@@ -769,6 +773,10 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
     //  issues for the few lanes it fills: such fields refill only empty waves.  Scheduling only: results never depend on it.)
     Tuning tn = c->tune;
     if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : 16;
+    if (c->voxelHaloEvent) {                 // the first reader of the halo's voxels
+      HIP_TRY(c, hipStreamWaitEvent(s, c->voxelHaloEvent, 0));
+      c->voxelHaloEvent = nullptr;
+    }
     HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, tn, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
   }
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
@@ -944,16 +952,14 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result 
   return finish_result(c, res);
 }
 
-// ---- one step without a host round trip between count and emit (the multi-GPU steady state) -------------------------
-int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
-                         const cuberille_slab *slab, const void **dev_row, size_t *row_bytes) {
-  int rc = validate(c, img, dev_voxels, prm);
-  if (rc) return rc;
-  if (!dev_row || !row_bytes) return fail(c, CUBERILLE_ERR_ARGUMENT, "null row pointer");
-  rc = count_prepare(c, img, dev_voxels, prm, slab);
-  if (rc) return rc;
-  rc = classify_slab(c, img, slab);
-  if (rc) return rc;
+}  // extern "C"
+
+namespace {
+
+// Everything of a step behind the sweep, launched without waiting: count + scan (+ gate), and the part of the emit that
+// needs no id offset.  The slab's bit volume and slice occupancy are complete on the stream when this is called.
+int step_launch(cuberille_ctx *c, const void **dev_row, size_t *row_bytes) {
+  int rc;
   // blind launches need: the sizes of a previous extraction on this context, the default projection branch and every
   // scratch table (the vertex-word queue is set up by count_prepare; the others are checked below)
   const bool blind = c->haveHistory && c->w.vqueue && !c->tune.no_cmap && !c->tune.no_heads && c->tune.points_variant == 3 &&
@@ -1002,6 +1008,54 @@ int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, cons
   *dev_row = c->w.totals;
   *row_bytes = sizeof(Totals);
   return CUBERILLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- one step without a host round trip between count and emit (the multi-GPU steady state) -------------------------
+int cuberille_step_begin(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
+                         const cuberille_slab *slab, const void **dev_row, size_t *row_bytes) {
+  int rc = validate(c, img, dev_voxels, prm);
+  if (rc) return rc;
+  if (!dev_row || !row_bytes) return fail(c, CUBERILLE_ERR_ARGUMENT, "null row pointer");
+  rc = count_prepare(c, img, dev_voxels, prm, slab);
+  if (rc) return rc;
+  rc = classify_slab(c, img, slab);
+  if (rc) return rc;
+  return step_launch(c, dev_row, row_bytes);
+}
+
+int cuberille_step_classify(cuberille_ctx *c, const cuberille_image_desc *img, const void *dev_voxels, const cuberille_params *prm,
+                            const cuberille_slab *slab, uint64_t **dev_bits, size_t *words_per_slice) {
+  int rc = validate(c, img, dev_voxels, prm);
+  if (rc) return rc;
+  if (!dev_bits || !words_per_slice) return fail(c, CUBERILLE_ERR_ARGUMENT, "null bit-plane pointer");
+  rc = count_prepare(c, img, dev_voxels, prm, slab);
+  if (rc) return rc;
+  if (slab && slab->voxels_ready_event) HIP_TRY(c, hipStreamWaitEvent(c->stream, (hipEvent_t)slab->voxels_ready_event, 0));
+  HIP_TRY(c, launch_classify(img->pixel_type, c->w, c->g, c->prm, c->g.oz0, c->g.oz1, c->tune, c->stream));
+  c->stepMode = 3;
+  *dev_bits = (uint64_t *)c->bits.p;
+  *words_per_slice = (size_t)c->g.ny * c->g.W;
+  return CUBERILLE_OK;
+}
+
+int cuberille_step_count(cuberille_ctx *c, void *halo_bits_event, void *halo_voxels_event, const void **dev_row, size_t *row_bytes) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (!dev_row || !row_bytes) return fail(c, CUBERILLE_ERR_ARGUMENT, "null row pointer");
+  if (c->stepMode != 3) return fail(c, CUBERILLE_ERR_STATE, "cuberille_step_count follows cuberille_step_classify");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->stepMode = 0;
+  if (halo_bits_event) HIP_TRY(c, hipStreamWaitEvent(c->stream, (hipEvent_t)halo_bits_event, 0));
+  // which of the halo slices hold an inside voxel (quirk Q1 looks at it): from the planes that came in
+  HIP_TRY(c, launch_occupancy_range(c->w, c->g, 0, c->g.oz0, c->stream));
+  HIP_TRY(c, launch_occupancy_range(c->w, c->g, c->g.oz1, c->g.nzb, c->stream));
+  c->voxelHaloEvent = (hipEvent_t)halo_voxels_event;
+  const int rc = step_launch(c, dev_row, row_bytes);
+  if (rc) c->voxelHaloEvent = nullptr;
+  return rc;
 }
 
 }  // extern "C"

@@ -158,6 +158,7 @@ struct Gate {
 hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, const Params &p, int z0, int z1, const Tuning &t,
                            hipStream_t s);
 hipError_t launch_occupancy(int pixel_type, const Workspace &w, const Grid &g, const Tuning &t, hipStream_t s);
+hipError_t launch_occupancy_range(const Workspace &w, const Grid &g, int z0, int z1, hipStream_t s);
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s);
 hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, int dyn, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,

@@ -2342,6 +2342,15 @@ hipError_t launch_occupancy(int pixel_type, const Workspace &w, const Grid &g, c
   return hipGetLastError();
 }
 
+// ... and for slices [z0, z1) whose bits did not come out of this context's sweep (the planes a neighbour rank sent:
+// cuberille_step_count)
+hipError_t launch_occupancy_range(const Workspace &w, const Grid &g, int z0, int z1, hipStream_t s) {
+  if (z1 <= z0) return hipSuccess;
+  const size_t wps = (size_t)g.ny * g.W;
+  hipLaunchKernelGGL(k_occupancy, dim3(z1 - z0), dim3(256), 0, s, w.bits + (size_t)z0 * wps, wps, w.sliceOcc + z0);
+  return hipGetLastError();
+}
+
 hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;

@@ -262,6 +262,24 @@ class Extractor:
             C.byref(slab) if slab is not None else None, C.byref(p), C.byref(n)))
         return p.value, int(n.value)
 
+    def step_classify(self, dev_ptr, desc, params, slab=None):
+        """First half of step_begin for the bits-first halo (cuberille_step_classify): thresholds the owned slices and
+        returns (device pointer of the buffer's bit volume, words per slice) without waiting."""
+        check_iso(int(desc.pixel_type), params)
+        p, n = C.c_void_p(), C.c_size_t()
+        _abi.check(self._ctx, self._lib.cuberille_step_classify(
+            self._ctx, C.byref(desc), C.c_void_p(dev_ptr), C.byref(params),
+            C.byref(slab) if slab is not None else None, C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
+    def step_count(self, halo_bits_event=None, halo_voxels_event=None):
+        """Second half (cuberille_step_count): the count behind halo_bits_event, the walk behind halo_voxels_event (raw
+        hipEvent_t handles, e.g. torch.cuda.Event.cuda_event; None: nothing to wait for).  Returns the row like step_begin."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _abi.check(self._ctx, self._lib.cuberille_step_count(
+            self._ctx, C.c_void_p(halo_bits_event or 0), C.c_void_p(halo_voxels_event or 0), C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
     def step_end(self, dev_rows, n_ranks, rank):
         """The cells with the id offset computed on the device from the gathered rows, then the one wait of the step.
         Returns (result, done): done is False (CUBERILLE_RETRY) when a flag on some rank sends every rank to the

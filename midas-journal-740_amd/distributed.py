@@ -254,7 +254,8 @@ class ShardedExtractor:
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
-                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None, close_steps=False):
+                 cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None, close_steps=False,
+                 bits_first=False):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
@@ -270,6 +271,11 @@ class ShardedExtractor:
         (cuberille_step_begin / _end) -- the all-gather of the per-rank rows lands in device memory and the cell pass sums
         its id offset there; the host waits once per step.  A flag in any row (quirk Q1 across slabs, counts beyond the
         sizes guessed from the previous step, an escaped walk) sends every rank through the synchronous protocol.
+        bits_first (with device_offsets): the neighbours get the inside BITS of the boundary slices right behind the
+        sweep of the owned slices (1/32 of a float32 slice's bytes, on a communicator of their own), the count waits only
+        for those; the halo's voxels, sent from the start of the step, are waited for by the projection walk alone
+        (cuberille_step_classify / cuberille_step_count).  All ranks must construct their ShardedExtractor together: a
+        second process group is made for the bit planes.
         close_steps: end every one-wait step in a gather of the ranks' outcomes, so that a failure inside
         cuberille_step_end is raised on every rank (one more collective and host wait per step).
         bounds: the ranks' slices [(z0, z1)] (contiguous, in rank order) instead of slabs of equal thickness -- e.g.
@@ -318,13 +324,19 @@ class ShardedExtractor:
         self.counts = None
         self.device_offsets = bool(device_offsets)
         self.close_steps = bool(close_steps)
+        self.bits_first = bool(bits_first) and world > 1
+        self._bits_group = None
+        self._side = None                         # bits_first: side streams and events of the two exchanges
+        if self.bits_first:
+            import torch.distributed as dist
+            self._bits_group = dist.new_group(backend=dist.get_backend(group))
         self.force_step_path = False              # tests: the one-wait step over CPU tensors and gloo (a stand-in extractor)
         self._lib_stream = None                   # device_offsets: the library's work goes to a torch stream of ours
         self._rows = None
         self._lazy_counts = None
         self._ev = None
         # what the last extract() cost besides kernels (bench.py prints them)
-        self.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+        self.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
 
     # -- halo exchange -------------------------------------------------------------------------------------------
     def _exchange(self, buf, halo, held, slab):
@@ -362,7 +374,7 @@ class ShardedExtractor:
         Runs halo exchange, count, the count all-gather and emit; leaves this rank's mesh part on its device."""
         import torch
         from .cuberille import required_halo
-        self.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+        self.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
         if self.world == 1:
             # (cuberille_extract_device is the one-wait step with a single rank: from the second extraction on a context
             #  on, everything is launched back to back and the host waits once.  The library runs on a stream of its own:
@@ -413,15 +425,19 @@ class ShardedExtractor:
             base = buf[self.tlo - self.lo:self.thi - self.lo]
         else:
             slab, desc, halo, base = self.slab, self.desc, self.halo, buf
-        keep = self._exchange(buf, halo, 0, slab)
-        if cuda and slab.voxels_ready_event is None:
-            ls.wait_stream(cur)                    # (host-waited exchange: the buffer is ready, order the streams all the same)
         failed = None
         try:
-            ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
+            if self.bits_first and hasattr(self.ex, "step_classify"):
+                ptr, nbytes, keep = self._begin_bits_first(buf, base, desc, params, slab, halo, dev, cur, ls)
+            else:
+                keep = self._exchange(buf, halo, 0, slab)
+                if cuda and slab.voxels_ready_event is None:
+                    ls.wait_stream(cur)            # (host-waited exchange: the buffer is ready, order the streams all the same)
+                ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
             nw = nbytes // 8
             row = _words_view(ptr, nw, dev)
         except _abi.CuberilleError as e:
+            keep = None
             failed = e
             row = torch.from_numpy(_abi.failed_row().view(np.int64).copy()).to(dev)
             nw = row.numel()
@@ -442,6 +458,9 @@ class ShardedExtractor:
         if cuda:
             self._ev[1].record(cur)
             ls.wait_event(self._ev[1])
+            if self._side is not None:             # bits_first: whatever the caller does to the buffer next comes behind both exchanges
+                cur.wait_stream(self._side[0])
+                cur.wait_stream(self._side[1])
         res, done, end_failed = None, False, None
         if failed is None:
             try:
@@ -468,6 +487,113 @@ class ShardedExtractor:
         # failed has no count: it only carries its failure into the gather, where every rank raises)
         return self._extract_sync(buf, params, thin, held=halo,
                                   resume=(int(res.n_points), int(res.n_cells)) if failed is None else None, failed=failed)
+
+    def _exchange_planes(self, bits_ptr, wps, z_begin, recvs, sends, dev, group, wait):
+        """The inside-bit planes of the halo: sends views of the library's bit volume (owned slices), receives straight into
+        it (halo slices).  Slice z (global) is the wps words at bits_ptr + (z - z_begin) * wps * 8."""
+        import torch
+        import torch.distributed as dist
+
+        def plane(a, b):
+            if bits_ptr is None:       # this rank's sweep failed: its neighbours still get (and send) their planes
+                return torch.zeros((b - a) * wps, dtype=torch.int64, device=dev)
+            return _words_view(bits_ptr + (a - z_begin) * wps * 8, (b - a) * wps, dev)
+        staged = dev.type == "cuda" and dist.get_backend(group) == "gloo" and wait
+        ops, keep, landed = [], [], []
+        for peer, a, b in recvs:
+            t = torch.empty((b - a) * wps, dtype=torch.int64) if staged else plane(a, b)
+            landed.append((t, a, b))
+            ops.append(dist.P2POp(dist.irecv, t, peer, group))
+        for peer, a, b in sends:
+            t = plane(a, b).cpu() if staged else plane(a, b)
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer, group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if not wait:
+            return reqs, keep
+        for req in reqs:
+            req.wait()
+        if staged:
+            for t, a, b in landed:
+                plane(a, b).copy_(t)
+        return [], keep
+
+    def _begin_bits_first(self, buf, base, desc, params, slab, halo, dev, cur, ls):
+        """The first half of a one-wait step with the bits-first halo.  Returns (row pointer, row bytes, tensors to keep
+        alive until the step is over).
+
+            side stream V : wait voxels_ready; halo VOXELS over the main communicator ........ record halo_voxels
+            library       : wait voxels_ready; sweep of the owned slices; record bits_ready
+            side stream B : wait bits_ready; halo BIT PLANES over the second communicator; record halo_bits
+            library       : wait halo_bits; count, scan, gate, heads, vertex scatter; wait halo_voxels; walk
+        """
+        import torch
+        import torch.distributed as dist
+        from . import _abi
+        cuda = dev.type == "cuda"
+        slice_bytes = self.nx * self.ny * self.itemsize
+        wps = self.ny * ((self.nx + 63) // 64)
+        recvs, sends = halo_transfers(self.nz, self.world, self.rank, halo, 0, self.bounds)
+        self.stats["halo_bytes"] += sum(b - a for _, a, b in recvs) * slice_bytes
+        self.stats["halo_bit_bytes"] += sum(b - a for _, a, b in recvs) * wps * 8
+        z_begin = int(slab.z_begin)
+        if cuda and (dist.get_backend(self.group) == "nccl" or self.force_event_path):
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev),
+                              torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+            sV, sB, ev_vox, ev_halo_vox, ev_bits, ev_halo_bits = self._side
+            ev_vox.record(cur)
+            slab.voxels_ready_event = ev_vox.cuda_event
+            slab.halo_ready_event = None
+            sV.wait_event(ev_vox)
+            with torch.cuda.stream(sV):
+                reqs, keep_v = exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group,
+                                              wait=False, halo=halo, global_nz=self.nz, held=0, ranges=self.bounds)
+                for req in reqs:
+                    req.wait()                 # orders side stream V behind the transfer, not the host
+                ev_halo_vox.record(sV)
+            bits_ptr, swept = None, None
+            try:
+                bits_ptr, got = self.ex.step_classify(base.data_ptr(), desc, params, slab)
+                assert got == wps
+                ev_bits.record(ls)
+                sB.wait_event(ev_bits)
+            except _abi.CuberilleError as e:       # the neighbours are on their way into the plane exchange: take part, then fail
+                swept = e
+            with torch.cuda.stream(sB):
+                reqs, keep_b = self._exchange_planes(bits_ptr, wps, z_begin, recvs, sends, dev, self._bits_group, wait=False)
+                for req in reqs:
+                    req.wait()
+                ev_halo_bits.record(sB)
+            if swept is not None:
+                raise swept
+            ptr, nbytes = self.ex.step_count(ev_halo_bits.cuda_event, ev_halo_vox.cuda_event)
+            return ptr, nbytes, (keep_v, keep_b)
+        # host-waited exchanges (gloo: CPU stand-ins, or several ranks rehearsing on one GPU)
+        slab.voxels_ready_event = None
+        slab.halo_ready_event = None
+        if cuda:
+            cur.synchronize()
+            self.stats["host_syncs"] += 1
+        bits_ptr, swept = None, None
+        try:
+            bits_ptr, got = self.ex.step_classify(base.data_ptr(), desc, params, slab)
+            assert got == wps
+        except _abi.CuberilleError as e:
+            swept = e
+        if cuda:
+            ls.synchronize()
+            self.stats["host_syncs"] += 1
+        _, keep_b = self._exchange_planes(bits_ptr, wps, z_begin, recvs, sends, dev, self._bits_group, wait=True)
+        exchange_halos(buf, self.lo, self.hi, self.z0, self.z1, self.rank, self.world, self.group, halo=halo,
+                       global_nz=self.nz, held=0, ranges=self.bounds)
+        if cuda:
+            cur.synchronize()
+            ls.wait_stream(cur)
+        if swept is not None:
+            raise swept
+        ptr, nbytes = self.ex.step_count(None, None)
+        return ptr, nbytes, keep_b
 
     def _extract_sync(self, buf, params, thin, held, resume=None, failed=None):
         """One step with the host in the loop: exchange, count, (vertex phase), all-gather of the counts, cells.

@@ -329,8 +329,9 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
         prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=relax, max_steps=100)
         # mode: "sync" the host in the loop; "step" device-resident offsets (cuberille_step_begin / _end);
         # "thin" / "step_thin": the same with the thin halo (walks that leave it are put aside and walked again)
+        # "..._bits": the bits-first halo (the neighbours' bit planes right behind the owned sweep, their voxels for the walk alone)
         sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm,
-                              thin_halo="thin" in mode, device_offsets=mode.startswith("step"))
+                              thin_halo="thin" in mode, device_offsets=mode.startswith("step"), bits_first=mode.endswith("_bits"))
         sh.force_event_path = bool(event_path)
         if relax == 0.95:
             assert sh.halo == (8 if step == 0.24 else 13)
@@ -380,7 +381,9 @@ def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0
 @pytest.mark.parametrize("world,event_path,step,mode,relax", [
     (2, False, 0.24, "sync", 0.95), (3, False, 0.24, "step", 0.95), (2, True, 0.24, "step", 0.95), (4, False, 0.5, "sync", 0.95),
     (3, False, 0.24, "thin", 0.95), (2, True, 0.24, "step_thin", 0.95), (4, False, 0.5, "step_thin", 0.95),
-    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0), (4, False, 0.24, "step_balanced", 0.95)])
+    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0), (4, False, 0.24, "step_balanced", 0.95),
+    (2, False, 0.24, "step_bits", 0.95), (3, True, 0.24, "step_thin_bits", 0.95), (4, False, 0.5, "step_thin_bits", 0.95),
+    (2, True, 0.6, "step_thin_bits", 1.0)])
 def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step, mode, relax):
     """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
     place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
@@ -418,6 +421,12 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
         assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
     elif mode.startswith("step"):
         assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 2) for st in stats), stats
+        if mode.endswith("_bits"):
+            # a bit plane per halo slice: 1/8 of the uint8 voxels' bytes here (1/32 for float32), rounded up to words per row
+            wps = 40 * ((104 + 63) // 64)
+            assert all(st[-1]["halo_bit_bytes"] * (104 * 40) == st[-1]["halo_bytes"] * wps * 8 for st in stats
+                       if st[-1]["halo_bytes"] and not st[-1]["deep_halo_fetched"]), stats
+            assert all(st[-1]["halo_bit_bytes"] > 0 for st in stats), stats
 
     class M:
         pass
@@ -896,7 +905,7 @@ try:
         assert (r3.n_points, r3.n_cells) == (res.n_points, res.n_cells)
         assert np.array_equal(got.cells, want.cells) and np.array_equal(got.points.view(np.uint32), want.points.view(np.uint32))
         assert sh2.stats["collectives"] == 1 and sh2.stats["host_syncs"] == 1, sh2.stats
-        sh2.stats = {"halo_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+        sh2.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
     ex2.close()
     print("RCCL_SMOKE_OK", int(res.n_points), int(res.n_cells))
 finally:
