@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--workload", default="marschner_lobb")
+    ap.add_argument("--opt", action="append", default=[], help="name=value for cuberille_debug_set_option on every context")
     args = ap.parse_args()
     import torch
     import bench
@@ -37,8 +38,11 @@ def main():
     prm = pkg.make_params(iso, triangles=True, project=True, threshold=thr, step=0.25, relax=0.95, max_steps=50)
     ctx = [pkg.Extractor(0) for _ in range(3)]
     for ex in ctx:
+        for kv in args.opt:
+            ex.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
         for _ in range(3):
             res = ex.extract_device(vol.data_ptr(), desc, prm)
+    print("options %s" % args.opt)
     print("one extraction: %d points, %d cells, device %.4f ms" % (res.n_points, res.n_cells, res.ms_total), flush=True)
 
     def one_by_one(k):
