@@ -62,7 +62,7 @@ WORKLOADS = {
 
 
 # the rocprofv3 PMC summary (profiles/collect.sh) of exactly the configuration a line reports: workload, edge -> file
-PMC_FILES = {("marschner_lobb", 1024): "r3_pmc_hbm.csv", ("sphere", 512): "r3_config3_sphere512_pmc_hbm.csv"}
+PMC_FILES = {("marschner_lobb", 1024): "r4_pmc_hbm.csv", ("sphere", 512): "r4_config3_sphere512_pmc_hbm.csv"}
 PASS_KERNELS = ("k_classify_span<float", "k_classify_flat<float", "k_count<", "k_block_scan")
 
 
@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--partition", default="balanced", choices=["balanced", "uniform"],
                     help="N>1: z-slabs of equal WORK, cut from the per-slice work a calibration step measures before the "
                          "timed region (default), or of equal thickness")
+    ap.add_argument("--no-warm-up", action="store_true",
+                    help="skip cuberille_warm_up (its toy extraction launches a few tiny kernels: profiles/collect.sh keeps them out "
+                         "of the per-kernel averages this way; the untimed warm-up steps do the warming then)")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="N=1: skip the extra measurement of one 1/8 slab (what a rank of an 8-GPU run does per step)")
     args = ap.parse_args()
@@ -266,7 +269,8 @@ def main():
                           max_steps=50)
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
                           device_offsets=not args.host_offsets, bits_first=not args.voxels_first and not args.host_offsets)
-    ex.warm_up(sh.desc)             # code objects, workspace and staging ring for this rank's buffer: before any step
+    if not args.no_warm_up:
+        ex.warm_up(sh.desc)         # code objects, workspace and staging ring for this rank's buffer: before any step
     period = None if strong else n
     if args.workload == "sphere" and not strong:
         raise SystemExit("sphere workload: strong scaling or one GPU only")

@@ -862,29 +862,44 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
 // (Totals::go) when the counts fit what they were sized for and no flag of the count stands.
 __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blockTot, u64 *__restrict__ blockBase, u32 nblk,
                                                      size_t g0, Totals *__restrict__ tot, Gate gate,
-                                                     const u32 *__restrict__ sliceOcc, int cz0, int oz0, int oz1, long long zglob0) {
+                                                     const u32 *__restrict__ sliceOcc, int cz0, int oz0, int oz1, long long zglob0,
+                                                     int slab) {
   constexpr int ROWS = 8;
   __shared__ u64 waveSum[16];
   __shared__ int firstOcc, topOcc, top2Occ;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // the three slices of the row (row_flags): first occupied slice of the counted range, highest and second-highest
-  // occupied owned slice
-  if (tid == 0) { firstOcc = 0x7fffffff; topOcc = -1; top2Occ = -1; }
-  __syncthreads();
-  for (int z = cz0 + tid; z < oz1; z += 1024)
-    if (sliceOcc[z]) {
-      atomicMin(&firstOcc, z);
-      if (z >= oz0) atomicMax(&topOcc, z);
+  // the three slices of a SLAB's row (row_flags; a whole volume has no neighbours to tell): first occupied slice of the
+  // counted range, highest and second-highest occupied owned slice.  Wave reductions, then one LDS atomic per wave.
+  if (slab) {
+    auto wave_min = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o < v ? o : v; } return v; };
+    auto wave_max = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o > v ? o : v; } return v; };
+    if (tid == 0) { firstOcc = 0x7fffffff; topOcc = -1; top2Occ = -1; }
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (int z = cz0 + tid; z < oz1; z += 1024)
+      if (sliceOcc[z]) {
+        lo = z < lo ? z : lo;
+        if (z >= oz0) hi = z;                      // (ascending: the last one is this thread's highest)
+      }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0 && lo != 0x7fffffff) atomicMin(&firstOcc, lo);
+    if (lane == 0 && hi >= 0) atomicMax(&topOcc, hi);
+    __syncthreads();
+    const int top = topOcc;
+    int second = -1;
+    for (int z = oz0 + tid; z < top; z += 1024)
+      if (sliceOcc[z]) second = z;
+    second = wave_max(second);
+    if (lane == 0 && second >= 0) atomicMax(&top2Occ, second);
+    __syncthreads();
+    if (tid == 0) {
+      tot->aliasZ = firstOcc == 0x7fffffff ? -1 : (int)(zglob0 + firstOcc);
+      tot->topZ = top < 0 ? -1 : (int)(zglob0 + top);
+      tot->top2Z = top2Occ < 0 ? -1 : (int)(zglob0 + top2Occ);
     }
-  __syncthreads();
-  const int top = topOcc;
-  for (int z = oz0 + tid; z < top; z += 1024)
-    if (sliceOcc[z]) atomicMax(&top2Occ, z);
-  __syncthreads();
-  if (tid == 0) {
-    tot->aliasZ = firstOcc == 0x7fffffff ? -1 : (int)(zglob0 + firstOcc);
-    tot->topZ = top < 0 ? -1 : (int)(zglob0 + top);
-    tot->top2Z = top2Occ < 0 ? -1 : (int)(zglob0 + top2Occ);
+  } else if (tid == 0) {
+    tot->aliasZ = tot->topZ = tot->top2Z = -1;
   }
   u64 runV = 0, runQ = 0;
   for (u32 base = 0; base < nblk; base += 1024 * ROWS) {
@@ -2371,7 +2386,8 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals, 0);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
-  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0);
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0,
+                     g.gnz != (long long)g.nzb ? 1 : 0);
   return hipGetLastError();
 }
 

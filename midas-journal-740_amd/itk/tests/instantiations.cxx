@@ -144,11 +144,87 @@ bool run(const char *name, bool triangles, unsigned long &points, unsigned long 
   return euler == 2 && points > 0;
 }
 
+// Ownership of the bulk-filled cells (txx:309-329 hands every cell to the mesh): the mesh must carry its cells through
+// DisconnectPipeline() and past the end of the filter (Testing/CuberilleTest01.cxx:161-162 takes the output and lets the
+// filter go), a second Update() of the same filter must replace them, and an output that is re-initialised must let go.
+static bool mesh_outlives_the_filter()
+{
+  typedef itk::Image<unsigned char, 3> ImageType;
+  typedef itk::Mesh<unsigned char, 3> MeshType;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType> FilterType;
+  const int n = 24;
+  ImageType::Pointer image = ImageType::New();
+  ImageType::RegionType region;
+  ImageType::IndexType start;
+  ImageType::SizeType size;
+  start.Fill(0);
+  size.Fill(n);
+  region.SetIndex(start);
+  region.SetSize(size);
+  image->SetRegions(region);
+  image->Allocate();
+  for (int z = 0; z < n; z++)
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++)
+        {
+        ImageType::IndexType idx;
+        idx[0] = x; idx[1] = y; idx[2] = z;
+        const double r = std::sqrt((x - 11.3) * (x - 11.3) + (y - 11.6) * (y - 11.6) + (z - 11.1) * (z - 11.1));
+        image->SetPixel(idx, static_cast<unsigned char>(r < 7.0 ? 200 : 0));
+        }
+  MeshType::Pointer kept;
+  unsigned long cells = 0, points = 0;
+  unsigned long long checksum = 0;
+  {
+    FilterType::Pointer filter = FilterType::New();
+    filter->SetInput(image);
+    filter->SetIsoSurfaceValue(100);
+    filter->Update();
+    const unsigned long first = filter->GetOutput()->GetNumberOfCells();
+    filter->SetGenerateTriangleFaces(false);          // a second run of the same filter: the first run's cells are replaced
+    filter->Update();
+    if (filter->GetOutput()->GetNumberOfCells() * 2 != first) return false;
+    filter->SetGenerateTriangleFaces(true);
+    filter->Update();
+    kept = filter->GetOutput();
+    kept->DisconnectPipeline();
+    cells = kept->GetNumberOfCells();
+    points = kept->GetNumberOfPoints();
+    if (cells != first || cells == 0) return false;
+    for (unsigned long c = 0; c < cells; c++)
+      {
+      MeshType::CellAutoPointer cell;
+      kept->GetCell(c, cell);
+      MeshType::CellType::PointIdConstIterator it = cell->PointIdsBegin();
+      for (unsigned int i = 0; i < cell->GetNumberOfPoints(); i++) checksum = checksum * 1000003ull + it[i];
+      }
+  }                                                   // the filter (and its GPU context) is gone
+  unsigned long long again = 0;
+  for (unsigned long c = 0; c < cells; c++)
+    {
+    MeshType::CellAutoPointer cell;
+    if (!kept->GetCell(c, cell) || cell->GetNumberOfPoints() != 3) return false;
+    MeshType::CellType::PointIdConstIterator it = cell->PointIdsBegin();
+    for (unsigned int i = 0; i < 3; i++)
+      {
+      if (it[i] >= points) return false;
+      again = again * 1000003ull + it[i];
+      }
+    }
+  if (again != checksum) return false;
+  kept->Initialize();                                 // lets go of the cell pointers; the slab goes with the mesh
+  if (kept->GetNumberOfCells() != 0) return false;
+  kept = 0;
+  std::cout << "mesh-outlives-filter " << points << " " << cells << " 2" << std::endl;
+  return true;
+}
+
 int main()
 {
   try
     {
     bool ok = true;
+    ok &= mesh_outlives_the_filter();
     unsigned long p[9], c[9];
     ok &= run<unsigned char>("uchar", false, p[0], c[0]);
     ok &= run<short>("short", false, p[1], c[1]);

@@ -14,11 +14,11 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 FAIL=0
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > "$OUT/bench.json" 2> "$OUT/stats.err" \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0 --no-slab-probe --no-warm-up "$@" > "$OUT/bench.json" 2> "$OUT/stats.err" \
   && echo "stats pass done" || { echo "stats pass FAILED (see $OUT/stats.err)"; FAIL=1; }
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/fetch.err" \
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe --no-warm-up "$@" > /dev/null 2> "$OUT/fetch.err" \
   && echo "FETCH_SIZE pass done" || { echo "FETCH_SIZE pass FAILED (see $OUT/fetch.err)"; FAIL=1; }
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/write.err" \
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$R/bench.py" --steps 1 --warmup 2 --cpu-sample 0 --no-slab-probe --no-warm-up "$@" > /dev/null 2> "$OUT/write.err" \
   && echo "WRITE_SIZE pass done" || { echo "WRITE_SIZE pass FAILED (see $OUT/write.err)"; FAIL=1; }
 python3 "$R/profiles/summarize.py" "$OUT" "$R/gpurun_out/$TAG" || { echo "summarize.py FAILED"; FAIL=1; }
 # the raw traces are tens of MiB per pass (gpurun brings back 64 MiB at most): the summaries are what is kept -- of a

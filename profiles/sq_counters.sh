@@ -9,9 +9,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d "$OUT/a" -o a -- python3 "$R/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/a.err"
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d "$OUT/a" -o a -- python3 "$R/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --no-slab-probe --no-warm-up "$@" > /dev/null 2> "$OUT/a.err"
 echo "pass 1 done"
-rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/b" -o b -- python3 "$R/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --no-slab-probe "$@" > /dev/null 2> "$OUT/b.err"
+rocprofv3 --kernel-trace --kernel-include-regex cuberille --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/b" -o b -- python3 "$R/bench.py" --steps 1 --warmup 1 --cpu-sample 0 --no-slab-probe --no-warm-up "$@" > /dev/null 2> "$OUT/b.err"
 echo "pass 2 done"
 python3 - "$OUT" "$R/gpurun_out/${TAG}_sq_counters.txt" "$*" <<'PY'
 import collections, csv, glob, os, sys

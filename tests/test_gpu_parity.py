@@ -699,9 +699,11 @@ def test_cxx_dropin_instantiates_for_other_pixel_types():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr[-500:])
     lines = r.stdout.strip().splitlines()
-    # 10 pixel-type instantiations (long / unsigned long / long long among them) + the user-defined interpolator type
-    # (host walk == GPU walk, quads and triangles)
-    assert len(lines) == 12 and all(l.split()[3] == "2" for l in lines)
+    # the mesh that outlives its filter (cells in one slab the mesh carries in its MetaDataDictionary), 10 pixel-type
+    # instantiations (long / unsigned long / long long among them) + the user-defined interpolator type (host walk == GPU
+    # walk, quads and triangles)
+    assert len(lines) == 13 and all(l.split()[3] == "2" for l in lines)
+    assert lines[0].startswith("mesh-outlives-filter")
 
 
 def test_noise_u8_config5_properties(pkg, extractor):
