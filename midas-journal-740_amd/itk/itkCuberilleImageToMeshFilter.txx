@@ -11,6 +11,9 @@
 
 #include <cmath>
 #include <cstdlib>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 #include <ctime>
 #include <new>
 #include <string>
@@ -65,8 +68,10 @@ template <class F> void ParallelRanges(uint64_t n, F f, unsigned int nT = 0)
 #if __cplusplus >= 201103L
   if (nT == 0)
     {
+    // (plain copies into fresh memory: what they wait for is the page faults of the destination, which more threads take
+    //  in parallel -- 16 on a host with cores to spare)
     const unsigned int hw = std::thread::hardware_concurrency();
-    nT = n < 65536 ? 1u : (hw >= 16 ? 8u : (hw >= 2 ? hw / 2 : 1u));
+    nT = n < 65536 ? 1u : (hw >= 64 ? 16u : (hw >= 16 ? 8u : (hw >= 2 ? hw / 2 : 1u)));
     }
   if (nT > 1 && n >= nT)
     {
@@ -105,12 +110,28 @@ public:
   TCell *Allocate(uint64_t n)
   {
     Release();
-    m_Cells = static_cast<TCell *>(::operator new(sizeof(TCell) * static_cast<size_t>(n ? n : 1)));
+    const size_t bytes = sizeof(TCell) * static_cast<size_t>(n ? n : 1);
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+    // a large slab on huge pages where the system offers them: 512 times fewer page faults under the filling threads
+    if (bytes >= (static_cast<size_t>(8) << 20))
+      {
+      void *p = 0;
+      if (posix_memalign(&p, static_cast<size_t>(2) << 20, bytes) == 0)
+        {
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        m_Cells = static_cast<TCell *>(p);
+        m_Malloced = true;
+        return m_Cells;
+        }
+      }
+#endif
+    m_Cells = static_cast<TCell *>(::operator new(bytes));
+    m_Malloced = false;
     return m_Cells;
   }
   void SetNumberOfConstructedCells(uint64_t n) { m_Constructed = n; }
 protected:
-  CellSlab() : m_Cells(0), m_Constructed(0) {}
+  CellSlab() : m_Cells(0), m_Constructed(0), m_Malloced(false) {}
   ~CellSlab() { Release(); }
 private:
   CellSlab(const Self &);
@@ -118,12 +139,14 @@ private:
   void Release()
   {
     for (uint64_t c = 0; c < m_Constructed; c++) m_Cells[c].~TCell();
-    ::operator delete(m_Cells);
+    if (m_Malloced) std::free(m_Cells);
+    else ::operator delete(m_Cells);
     m_Cells = 0;
     m_Constructed = 0;
   }
   TCell *m_Cells;
   uint64_t m_Constructed;
+  bool m_Malloced;
 };
 
 // Bulk form of the loop at txx:309-329: all cells of the mesh constructed in one slab, the cell container filled with
