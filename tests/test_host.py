@@ -359,3 +359,16 @@ def test_iso_value_of_64bit_pixels_is_cast_like_the_reference(pkg, oracle):
         assert np.array_equal(a.cells, other.cells) and np.array_equal(a.points.view(np.uint32), other.points.view(np.uint32))
     with pytest.raises(ValueError):
         oracle.run(small.astype(np.uint64), -1.0, **kw)
+
+
+def test_bulk_mesh_fill_under_sanitizers():
+    """The drop-in's mesh fill (all cells in one slab the mesh carries in its MetaDataDictionary, CellsAllocatedAsStaticArray:
+    what replaces the reference's heap object per face, txx:309-329) needs no GPU: itk/tests/mesh_fill.cxx built with
+    -fsanitize=address,undefined -- fill, read back, refill the same mesh, Initialize(), a mesh that outlives every other
+    owner, destruction; leaks count as failures (LeakSanitizer)."""
+    import subprocess
+    itk = os.path.join(ROOT, "midas-journal-740_amd", "itk")
+    exe = os.path.join(itk, "build", "mesh_fill_asan")
+    subprocess.check_call(["make", "-s", "-C", itk, "build/mesh_fill_asan"])
+    r = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "mesh fill ok" in r.stdout, (r.stdout[-300:], r.stderr[-2000:])
