@@ -205,9 +205,10 @@ def main():
     ap.add_argument("--full-halo", action="store_true", help="N>1: exchange the whole projection-reach halo every step")
     ap.add_argument("--host-offsets", action="store_true",
                     help="N>1: the count all-gather through the host (two more host waits per step) instead of device-resident rows")
-    ap.add_argument("--voxels-first", action="store_true",
-                    help="N>1: the count waits for the halo's VOXELS (round 3) instead of for their bit planes alone (the default: "
-                         "planes right behind the owned sweep, on a communicator of their own; only the walk waits for the voxels)")
+    ap.add_argument("--bits-first", action="store_true",
+                    help="N>1: the neighbours' BIT PLANES cross right behind the owned sweep, on a communicator of their own, and the "
+                         "count waits for those alone; only the walk waits for the halo's voxels (DESIGN.md section 6: rehearsed "
+                         "bit-identical, never run under RCCL -- a switch until a node has timed it against the default)")
     ap.add_argument("--opt", action="append", default=[],
                     help="development: name=value for cuberille_debug_set_option (kernel variants; results never depend on them)")
     ap.add_argument("--partition", default="balanced", choices=["balanced", "uniform"],
@@ -268,7 +269,7 @@ def main():
     prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
                           max_steps=50)
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
-                          device_offsets=not args.host_offsets, bits_first=not args.voxels_first and not args.host_offsets)
+                          device_offsets=not args.host_offsets, bits_first=args.bits_first and not args.host_offsets)
     if not args.no_warm_up:
         ex.warm_up(sh.desc)         # code objects, workspace and staging ring for this rank's buffer: before any step
     period = None if strong else n
@@ -301,7 +302,7 @@ def main():
         del buf
         sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
                               device_offsets=not args.host_offsets, bounds=bounds,
-                              bits_first=not args.voxels_first and not args.host_offsets)
+                              bits_first=args.bits_first and not args.host_offsets)
         buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
         buf[:sh.z0 - sh.lo].zero_()
         buf[sh.z1 - sh.lo:].zero_()
