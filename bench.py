@@ -139,6 +139,33 @@ def slab_probe(pkg, torch, ex, buf, n, dtype, prm, reps=20):
             "escaped_walks": int(escaped)}
 
 
+def series_probe(pkg, torch, ex, buf, desc, prm, device_index, volumes=20):
+    """A SERIES of volumes through two contexts (two streams), the next one's step opened (cuberille_step_begin returns without
+    waiting) before the previous one's is closed: the next sweep and the previous tail share the GPU.  Beside the line's
+    `value`, which stays one extraction after the other on one context.  Here the series is the resident volume again and
+    again; what it shows is the ceiling of overlapping the HBM-bound sweep with the f64-bound walk."""
+    ex2 = pkg.Extractor(device_index)
+    try:
+        for _ in range(2):             # both contexts with this volume's sizes behind them (the slab probe left others)
+            ex.extract_device(buf.data_ptr(), desc, prm)
+            ex2.extract_device(buf.data_ptr(), desc, prm)
+        ctx = (ex, ex2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        row = ctx[0].step_begin(buf.data_ptr(), desc, prm)[0]
+        for i in range(volumes):
+            nxt = ctx[(i + 1) & 1].step_begin(buf.data_ptr(), desc, prm)[0] if i + 1 < volumes else None
+            res, done = ctx[i & 1].step_end(row, 1, 0)
+            if not done:
+                return {"error": "a step came back with CUBERILLE_RETRY"}
+            row = nxt
+        dt = time.perf_counter() - t0
+        return {"volumes": volumes, "ms_per_volume": round(dt / volumes * 1e3, 4), "contexts": 2,
+                "points": int(res.n_points), "cells": int(res.n_cells)}
+    finally:
+        ex2.close()
+
+
 def cpu_baseline(pkg, torch, args, device, gpu_mesh=None, gpu_iterations=None):
     """The oracle restatement of the reference ("port"), timed on this box's host cores on a
     bounded sample of the same workload (the reference itself needs ITK).
@@ -461,6 +488,11 @@ def main():
                 out["slab_eighth_probe"] = slab_probe(pkg, torch, ex, buf, n, dtype, prm)
             except Exception as e:   # noqa: BLE001
                 out["slab_eighth_probe"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_slab_probe and n >= 256:
+            try:
+                out["series_two_contexts"] = series_probe(pkg, torch, ex, buf, sh.desc, prm, local_rank, max(args.steps, 10))
+            except Exception as e:   # noqa: BLE001
+                out["series_two_contexts"] = {"error": "%s: %s" % (type(e).__name__, e)}
         parity = None
         if world == 1 and args.cpu_sample > 0:
             parity, out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device, mesh, int(res.proj_iterations))
