@@ -123,6 +123,8 @@ struct Tuning {
   int no_cmap = 0, no_heads = 0, no_vqueue = 0, no_stream_classify = 0;   // drop a scratch table / the flat-stream path
   int classify_variant = 0;   // 0: staged spans with write-through stores where the volume is large, 1: always the plain sweep
   int classify_grid = 0;      // workgroups of the sweep (0 = default)
+  int classify_keep_tail = 0; // 1: a partly filled last round of spans stays with the span kernel (A/B of the balancing)
+  int proj_chunk64_below = 0; // vertices under which the walk deals batches of 64 (0: the default, 8 M)
   int points_no_split = 0;    // 1: the point pass runs one lane per vertex word however short the queue
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2

@@ -1387,7 +1387,9 @@ __device__ __forceinline__ bool locate_quad(const EmitArgs &a, const Grid &g, si
                                             int &y, int &z, int &f) {
   u32 r = 0;
   size_t gi;
-  if (a.headQ && (Q0 & 63) == 0) gi = locate_word_wave<16>(a, a.headQ, nwords, q + Q0, valid, r);
+  // (the head table is over ABSOLUTE outputs, the ghost slice's Q0 quads included: a wave whose first output is not a
+  //  multiple of 64 starts its window at the word of the multiple below it -- at or before its own first word)
+  if (a.headQ) gi = locate_word_wave<16>(a, a.headQ, nwords, q + Q0, valid, r);
   else gi = valid ? locate_word<16>(a, nwords, q + Q0, r) : 0;
   if (!valid) return false;
   int k;
@@ -2298,8 +2300,12 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       // word stores and more, smaller workgroups fill the chip better)
       u64 spanWords = 0;
       if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
-        const u64 nspans = nwordsAll / SPAN_WORDS;
+        u64 nspans = nwordsAll / SPAN_WORDS;
         const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU
+        // the workgroups take the spans in rounds; a last round that only a part of them has a span for costs a whole span's
+        // time all the same (a 134-slice slab of 1024^2 float32: 536 spans, 0.135 ms where 512 take 0.065): below two
+        // thirds of a round the rest goes to the plain sweep behind this launch, which runs at four fifths of the rate
+        if (nspans > want && (nspans % want) * 3 < want * 2 && !tn.classify_keep_tail) nspans -= nspans % want;
         const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
         hipLaunchKernelGGL((k_classify_span<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
         spanWords = nspans * SPAN_WORDS;
@@ -2373,7 +2379,10 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   if (tiled && g.W <= TILE_WMAX) {
     // (slices that are whole count blocks: a workgroup walks up a column of COUNT_ZRUN blocks and re-uses two of its three planes)
     const int want = tiled == 1 ? COUNT_ZRUN : tiled >= 4 ? tiled : 0;      // (tiled 2: one block per workgroup; >= 4: that run)
-    const int zrun = want && sliceWords % COUNT_WB == 0 && g.oz1 - g.cz0 >= 2 * want ? want : 0;
+    // (... where the columns are still enough workgroups to fill the chip: a 129-slice slab of 1024^2 gives 136 columns of 8,
+    //  0.107 ms against 0.05 one block per workgroup)
+    const bool columnsFill = want && (u64)(sliceWords / COUNT_WB) * (u64)((g.oz1 - g.cz0 + want - 1) / want) >= 1024;
+    const int zrun = want && sliceWords % COUNT_WB == 0 && g.oz1 - g.cz0 >= 2 * want && (columnsFill || tiled >= 4) ? want : 0;
     const unsigned grid = zrun ? (unsigned)(sliceWords / COUNT_WB) * (unsigned)((g.oz1 - g.cz0 + zrun - 1) / zrun) : blocks;
     hipLaunchKernelGGL((k_count<0, true, 512>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals, zrun);
@@ -2529,8 +2538,14 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   // chunk per wave: 256 -> 1.64 ms, 906 -> 1.93 ms, 3648 -> 2.40 ms; 64 without refill 2.76 ms)
   // (a launch that leaves wave slots empty -- every volume the reference ships -- deals 64 per wave: one vertex per lane, no
   //  refill, the kernel ends with its slowest walk instead of with a wave's second helping; nucleon 0.212 -> 0.163 ms wall)
-  u64 chunk = tn.proj_chunk <= 0 ? (nPoints <= 64ull * 4096 ? 64 : 128) : tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk;
+  // (... and up to a few batches of 128 per wave -- a slab of a multi-GPU run: 4.4 M vertices at 1024^3 -- batches of 64 spread
+  //  the tails of the waves' sequences better: 0.83 -> 0.74 ms there, 0.38 -> 0.33 at 1.6 M; at 11.1 M 128 wins by 2 %)
+  //  -- but only once batches of 64 fill the grid: between the two, 0.8 M vertices of a 512^3 sphere, 6170 waves that refill
+  //  from their 128 beat 12 340 that cannot, 0.172 against 0.187 ms)
   const u64 gridWaves = (u64)tn.proj_waves;
+  const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : 8000000ull;
+  u64 chunk = tn.proj_chunk > 0 ? (tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk)
+            : (nPoints <= 64ull * 4096 || (nPoints > 64 * (gridWaves ? gridWaves : 16384) && nPoints < upTo)) ? 64 : 128;
   while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
   u64 nwaves = (nPoints + chunk - 1) / chunk;
   if (gridWaves && nwaves > gridWaves) nwaves = gridWaves;
