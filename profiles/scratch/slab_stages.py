@@ -12,7 +12,7 @@ prm = pkg.make_params(0.5, triangles=True, project=True, threshold=0.002, step=0
 whole = pkg.make_desc(np.float32, (n, n, n))
 below, above = minimum_halo(whole, prm)
 for (a, b) in ((384, 512), (448, 512), (512, 640), (0, 1024)):
-    for opts in ((), ("count_variant=0",), ("count_variant=2",)):
+    for opts in ((), ("proj_handoff=0",), ("proj_handoff=8",), ("proj_handoff=32",), ("proj_handoff=16", "proj_resume_waves=1024"), ("proj_handoff=16", "proj_handoff_below=100000000")):
         ex = pkg.Extractor(0)
         for kv in opts:
             ex.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
