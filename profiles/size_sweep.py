@@ -1,11 +1,15 @@
+#!/usr/bin/env python3
+"""Per-stage device times over volume sizes and workloads (per-stage events on), with the rates that show where a launch shape
+stops fitting: GB/s of the sweep, ps per vertex / per pass of the walk, ps per quad of the cell pass.
+  python profiles/size_sweep.py [name=value ...]   (development switches of the context)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as g
 import bench
 pkg = g.load_package()
 dev = torch.device("cuda", 0)
-cases = [("sphere", n) for n in (256, 384, 512, 768, 1000)] + [("noise", n) for n in (256, 384, 512)] + [("marschner_lobb", n) for n in (256, 512, 768, 1024)]
+cases = [("sphere", n) for n in (128, 256, 384, 500, 512, 640, 768, 1000)] + [("noise", n) for n in (128, 256, 384, 512, 768)] + [("marschner_lobb", n) for n in (256, 512, 768, 1024)]
 opts = [kv for kv in sys.argv[1:]]
 print("options", opts, flush=True)
 for wl, n in cases:

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""What ONE rank of a multi-GPU run does per step, stage by stage, measured on this GPU: slabs of the 1024^3 Marschner-Lobb volume
+(THIN_HALO, through cuberille_step_begin / _end with itself as the only rank) beside the whole volume, under a few development
+switches.  python profiles/slab_stages.py"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as g
 import bench
@@ -12,7 +16,7 @@ prm = pkg.make_params(0.5, triangles=True, project=True, threshold=0.002, step=0
 whole = pkg.make_desc(np.float32, (n, n, n))
 below, above = minimum_halo(whole, prm)
 for (a, b) in ((384, 512), (448, 512), (512, 640), (0, 1024)):
-    for opts in ((), ("proj_handoff=0",), ("proj_handoff=8",), ("proj_handoff=32",), ("proj_handoff=16", "proj_resume_waves=1024"), ("proj_handoff=16", "proj_handoff_below=100000000")):
+    for opts in ((), ("classify_keep_tail=1",), ("count_variant=1",), ("proj_chunk=128",)):
         ex = pkg.Extractor(0)
         for kv in opts:
             ex.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
