@@ -126,6 +126,7 @@ struct Tuning {
   int classify_keep_tail = 0; // 1: a partly filled last round of spans stays with the span kernel (A/B of the balancing)
   int proj_chunk64_below = 0; // vertices under which the walk deals batches of 64 (0: the default, 8 M)
   int points_no_split = 0;    // 1: the point pass runs one lane per vertex word however short the queue
+  int points_split = 0;       // lanes per vertex word of the point pass: 1, 2, 4 or 8 (0: by the length of the queue)
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile (in columns of 8 blocks where slices are

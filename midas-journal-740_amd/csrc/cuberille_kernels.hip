@@ -2427,6 +2427,15 @@ hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, i
   return hipGetLastError();
 }
 
+// lanes per vertex word of the point pass (k_emit_points_dense<SPLIT>): its first phase walks a word's voxels serially, a
+// word on a flat face holds up to 128 vertices, and a short queue leaves wave slots empty -- more lanes per word there
+// (profiles/r4_size_sweep.log: Marschner-Lobb 256^3, 154 k vertex words, 0.089 ms with one lane per word, 0.036 with four;
+//  512^3, 630 k words, 0.096 against 0.068 with two; from 768^3 on one lane per word wins, as on every noise field above 256^3)
+static int points_split_for(u32 nVertexWords) {
+  // (a launch sized blindly passes its cover, a quarter above the previous extraction's queue)
+  return nVertexWords <= 32768u ? 8 : nVertexWords <= 200000u ? 4 : nVertexWords <= 900000u ? 2 : 1;
+}
+
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
                               const Tuning &tn, int dyn, hipStream_t s) {
   if (!nV) return hipSuccess;
@@ -2434,10 +2443,15 @@ hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo,
   EmitArgs a = emit_args(w, g, q1, 0);
   a.dyn = dyn;                                   // (only the queue form below is ever launched blindly)
   if (w.vqueue && nwords < 0xffffffffULL && tn.points_variant == 3) {
-    if (nVertexWords <= 32768u && !tn.points_no_split)
-      hipLaunchKernelGGL(k_emit_points_dense<8>, dim3(grid_for((u64)nVertexWords * 8, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
-    else
-      hipLaunchKernelGGL(k_emit_points_dense<1>, dim3(grid_for(nVertexWords, 256, 0)), dim3(256), 0, s, a, g, geo, w.vqueue, nVertexWords);
+    const int split = tn.points_split > 0 ? tn.points_split : (tn.points_no_split ? 1 : points_split_for(nVertexWords));
+#define CUBERILLE_LAUNCH_POINTS(SPLIT)                                                                                      \
+    hipLaunchKernelGGL(k_emit_points_dense<SPLIT>, dim3(grid_for((u64)nVertexWords * SPLIT, 256, 0)), dim3(256), 0, s, a, g, geo, \
+                       w.vqueue, nVertexWords)
+    if (split >= 8) CUBERILLE_LAUNCH_POINTS(8);
+    else if (split >= 4) CUBERILLE_LAUNCH_POINTS(4);
+    else if (split >= 2) CUBERILLE_LAUNCH_POINTS(2);
+    else CUBERILLE_LAUNCH_POINTS(1);
+#undef CUBERILLE_LAUNCH_POINTS
   } else
     hipLaunchKernelGGL(k_emit_points_wave, dim3(grid_for(nV, 256, 0)), dim3(256), 0, s, a, g, geo, nwords, nV);
   return hipGetLastError();
