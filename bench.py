@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--partition", default="balanced", choices=["balanced", "uniform"],
                     help="N>1: z-slabs of equal WORK, cut from the per-slice work a calibration step measures before the "
                          "timed region (default), or of equal thickness")
+    ap.add_argument("--calibration-rounds", type=int, default=2,
+                    help="N>1, --partition balanced: calibrate-and-cut rounds before the timed region (each on the cuts of the one before)")
     ap.add_argument("--no-warm-up", action="store_true",
                     help="skip cuberille_warm_up (its toy extraction launches a few tiny kernels: profiles/collect.sh keeps them out "
                          "of the per-kernel averages this way; the untimed warm-up steps do the warming then)")
@@ -322,20 +324,24 @@ def main():
         # the surface of a volume is rarely spread evenly over z (this field's rippled sheet lies in a sixth of the
         # slices): one calibration step on slabs of equal thickness measures what every slice costs, the slabs of the
         # timed region are cut for equal work.  Outside the timed region, like any warm-up; the same volume, other cuts.
+        # (a vertex does not cost the same everywhere -- the walks of this field's flat caps at the bottom of the volume run
+        #  out of steps, those of the sheet converge in a few passes: measured on one GPU, profiles/r4_slab_stages.log -- and a
+        #  rank's time is spread over its slices by vertices created: a second round on the first round's cuts refines them)
         from midas_journal_740_amd.distributed import balanced_bounds
         if res is None:
             res = sh.extract(buf, prm)
-        bounds = balanced_bounds(sh.slice_work(res), world)
-        del buf
-        sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
-                              device_offsets=not args.host_offsets, bounds=bounds,
-                              bits_first=args.bits_first and not args.host_offsets)
-        buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
-        buf[:sh.z0 - sh.lo].zero_()
-        buf[sh.z1 - sh.lo:].zero_()
-        torch.cuda.synchronize()
-        for _ in range(max(args.warmup, 2)):
-            res = sh.extract(buf, prm)
+        for _round in range(max(args.calibration_rounds, 1)):
+            bounds = balanced_bounds(sh.slice_work(res), world)
+            del buf
+            sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
+                                  device_offsets=not args.host_offsets, bounds=bounds,
+                                  bits_first=args.bits_first and not args.host_offsets)
+            buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
+            buf[:sh.z0 - sh.lo].zero_()
+            buf[sh.z1 - sh.lo:].zero_()
+            torch.cuda.synchronize()
+            for _ in range(max(args.warmup, 2)):
+                res = sh.extract(buf, prm)
         partition = "balanced"
     stage_keys = ["ms_classify", "ms_count", "ms_scan", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
     # the timed region carries the two event pairs every extraction has (the pass over the volume, the emit phase);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What ONE rank of a multi-GPU run does per step, stage by stage, measured on this GPU: slabs of the 1024^3 Marschner-Lobb volume
 (THIN_HALO, through cuberille_step_begin / _end with itself as the only rank) beside the whole volume, under a few development
-switches.  python profiles/slab_stages.py"""
+switches.  python profiles/slab_stages.py [z0:z1 ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,15 +15,16 @@ torch.cuda.synchronize()
 prm = pkg.make_params(0.5, triangles=True, project=True, threshold=0.002, step=0.25, relax=0.95, max_steps=50)
 whole = pkg.make_desc(np.float32, (n, n, n))
 below, above = minimum_halo(whole, prm)
-for (a, b) in ((384, 512), (448, 512), (512, 640), (0, 1024)):
-    for opts in ((), ("classify_keep_tail=1",), ("count_variant=1",), ("proj_chunk=128",)):
+ranges = [tuple(int(v) for v in r.split(":")) for r in sys.argv[1:]] or [(384, 512), (448, 512), (512, 640), (0, 1024)]
+for (a, b) in ranges:
+    for opts in ((), ("classify_keep_tail=1",), ("count_variant=1",), ("proj_chunk=128",)) if not sys.argv[1:] else ((),):
         ex = pkg.Extractor(0)
         for kv in opts:
             ex.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
         if (a, b) == (0, 1024):
             lo, hi, slab = 0, n, None
         else:
-            lo, hi = a - below - 1, b + above + 1
+            lo, hi = max(a - below - 1, 0), min(b + above + 1, n)
             slab = pkg._abi.Slab(n, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO, None, None)
         desc = pkg.make_desc(np.float32, (n, n, hi - lo))
         sub = vol[lo:hi]
