@@ -411,6 +411,7 @@ __device__ __forceinline__ void word_coords(const Grid &g, size_t gi, int &k, in
 // own address plus an offset that is 0 at the image border (ZeroFluxNeumann: the clamped neighbour is the row itself).
 struct WordPos {
   const u64 *q;                 // &bits[(z*ny + y)*W + k]
+  bool global;                  // q points into the bit volume itself (not into a staged copy): see centre_row
   int k, y, z;
   long long km, kp;             // -1 / +1, or 0 at the row ends
   long long yo[3], zo[3];       // word offsets of rows y-1, y, y+1 and slices z-1, z, z+1 (clamped)
@@ -419,6 +420,7 @@ struct WordPos {
 __device__ __forceinline__ WordPos word_pos(const u64 *__restrict__ bits, const Grid &g, int y, int z, int k) {
   WordPos w;
   w.q = bits + ((size_t)z * g.ny + y) * g.W + k;
+  w.global = true;
   w.k = k; w.y = y; w.z = z;
   w.km = k > 0 ? -1 : 0;
   w.kp = k < g.W - 1 ? 1 : 0;
@@ -433,6 +435,7 @@ __device__ __forceinline__ WordPos word_pos(const u64 *__restrict__ bits, const 
 __device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long below, long long above, const Grid &g, int y, int z, int k) {
   WordPos w;
   w.q = q;
+  w.global = false;
   w.k = k; w.y = y; w.z = z;
   w.km = k > 0 ? -1 : 0;
   w.kp = k < g.W - 1 ? 1 : 0;
@@ -442,12 +445,38 @@ __device__ __forceinline__ WordPos word_pos_tile(const u64 *q, long long below, 
   return w;
 }
 
-// the row at word offset `off` from the word: three unconditional loads (all loads of a neighbourhood are
-// independent and issue back to back, one memory latency in total), the selects are ALU
+// A word of the bit volume together with the two bits of its row neighbours that border it -- bit 63 of the word before,
+// bit 0 of the word behind -- in ONE 16-byte load: the four dwords from the upper half of the word before on (the kernels
+// that look at words are bound by the number of their vector-memory instructions, and this was three of them).  The
+// first word of a row starts the load at itself instead (its left neighbour is never looked at, and the very first word
+// of the volume has nothing before it); the word behind the last one of the buffer is the spare slice count_prepare
+// reserves.  4-byte aligned, like every dword of the volume.
+__device__ __forceinline__ void centre_row(const u64 *r, int k, u64 &c, u32 &prevHi, u32 &nextLo) {
+  // (ONE vector load of four dwords that is only 4-byte aligned: global_load_dwordx4 takes any dword address; as four
+  //  scalar loads the compiler, which knows the 8-byte phase, cuts them into dword + dwordx2 + dword)
+  typedef u32 Dwords4 __attribute__((ext_vector_type(4)));
+  typedef Dwords4 __attribute__((aligned(4))) Dwords4A4;
+  const u32 *p = reinterpret_cast<const u32 *>(r) - (k > 0 ? 1 : 0);
+  const Dwords4 v = *reinterpret_cast<const Dwords4A4 *>(p);
+  const u32 v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+  if (k > 0) { prevHi = v0; c = (u64)v1 | ((u64)v2 << 32); nextLo = v3; }
+  else { prevHi = 0u; c = (u64)v0 | ((u64)v1 << 32); nextLo = v2; }
+}
+
+// the row at word offset `off` from the word (a staged copy keeps its three separate reads: LDS)
 __device__ __forceinline__ Rows3 load_row(const WordPos &w, const Grid &g, long long off) {
   const u64 *r = w.q + off;
-  const u64 c = r[0], wp = r[w.km], wn = r[w.kp];
   Rows3 o;
+  if (w.global) {
+    u64 c;
+    u32 prevHi, nextLo;
+    centre_row(r, w.k, c, prevHi, nextLo);
+    o.c = c;
+    o.m = (c << 1) | (w.k > 0 ? (u64)(prevHi >> 31) : (c & 1ull));
+    o.p = (c >> 1) | (w.k < g.W - 1 ? ((u64)(nextLo & 1u) << 63) : (c & (1ull << g.lastpos)));
+    return o;
+  }
+  const u64 c = r[0], wp = r[w.km], wn = r[w.kp];
   o.c = c;
   o.m = (c << 1) | (w.k > 0 ? (wp >> 63) : (c & 1ull));
   o.p = (c >> 1) | (w.k < g.W - 1 ? (wn << 63) : (c & (1ull << g.lastpos)));
@@ -533,16 +562,24 @@ __device__ __forceinline__ u64 load_neigh(const WordPos &w, const Grid &g, Neigh
     n.exz[0] = w.z > 0 ? ~0u : 0u;            n.exz[1] = ~0u;  n.exz[2] = w.z < g.nzb - 1 ? ~0u : 0u;
   }
   u64 c[3][3];
+  u32 wpHi11, wnLo11;
+  const u32 *q32 = reinterpret_cast<const u32 *>(w.q);
 #pragma unroll
   for (int dz = 0; dz < 3; dz++)
 #pragma unroll
-    for (int dy = 0; dy < 3; dy++) c[dz][dy] = w.q[w.yo[dy] + w.zo[dz]];
+    for (int dy = 0; dy < 3; dy++)
+      if (dz != 1 || dy != 1) c[dz][dy] = w.q[w.yo[dy] + w.zo[dz]];
+  // the centre row's edge bits: always (they decide whether voxel 0 / 63 emits a face); with the word itself in one load
+  if (w.global) {
+    centre_row(w.q, w.k, c[1][1], wpHi11, wnLo11);
+  } else {
+    c[1][1] = w.q[0];
+    wpHi11 = q32[2 * w.km + 1];
+    wnLo11 = q32[2 * w.kp];
+  }
   const bool first = w.k == 0, last = w.k == g.W - 1;
   const bool ragged = g.lastpos != 63;           // uniform: the last word of a row is partly filled
   const u64 lastbit = 1ull << g.lastpos;
-  const u32 *q32 = reinterpret_cast<const u32 *>(w.q);
-  // the centre row's edge bits: always (they decide whether voxel 0 / 63 emits a face)
-  const u32 wpHi11 = q32[2 * w.km + 1], wnLo11 = q32[2 * w.kp];
   auto row = [&](u64 cc, u32 wpHi, u32 wnLo, u64 &m, u64 &p) {
     // border clamp (I2): off the row's ends the neighbour is the end voxel itself
     const u32 carryM = first ? ((u32)cc & 1u) : (wpHi >> 31);
@@ -1148,7 +1185,15 @@ __device__ __forceinline__ size_t locate_word_wave(const EmitArgs &a, const u32 
       // (the window lies in one count block or two: their bases through wave-uniform addresses, scalar loads)
       const size_t b0 = w0 >> COUNT_LG, b1 = b0 + 1 < a.nblk ? b0 + 1 : b0;
       const u64 bb0 = a.blockBase[2 * b0 + (SHIFT ? 1 : 0)], bb1 = a.blockBase[2 * b1 + (SHIFT ? 1 : 0)];
-      const u64 sp = a.segPre[w >> 6];
+      // (the window's 256 words lie in five 64-word segments at most: their prefixes through wave-uniform addresses --
+      //  scalar loads -- and a select per lane, instead of one more vector load)
+      const size_t s0 = w0 >> 6, sLast = (nwords - 1) >> 6;
+      u64 sp = a.segPre[s0];
+#pragma unroll
+      for (int i = 1; i < 5; i++) {
+        const u64 spi = a.segPre[s0 + i <= sLast ? s0 + i : sLast];
+        if ((w >> 6) == s0 + i) sp = spi;
+      }
       const u64 base = ((w >> COUNT_LG) == b0 ? bb0 : bb1) + (SHIFT ? (sp >> 32) : (sp & 0xffffffffull));
       const u32 p4[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
@@ -1323,9 +1368,7 @@ __global__ __launch_bounds__(256) void k_emit_points_dense(EmitArgs a, Grid g, G
 // the top corners of its source slice; an index >= totV names a vertex of the rank below (Grid::extAlias): entry
 // index - totV of the plane that rank sent, whose positions stand behind this rank's own points.
 template <bool MAP>
-__device__ __forceinline__ void quad_corners(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, u64 (&lid)[4]) {
-  u32 unk;
-  const int zp = alias_of(a.occ, g, a.q1, z, unk);
+__device__ __forceinline__ void quad_corners(const EmitArgs &a, const Grid &g, int x, int y, int z, int f, int zp, u64 (&lid)[4]) {
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int i = kFaceCorner[f][c];
@@ -1464,10 +1507,20 @@ __global__ __launch_bounds__(256) void k_emit_cells(EmitArgs a, Grid g, size_t n
     a.pointOffset += off;
   }
   const u64 V0 = a.tot->V0, Q0 = a.tot->Q0, totV = a.tot->totV;
-  int x, y, z, f;
-  if (locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f)) {
+  int x, y, z = 0, f;
+  const bool have = locate_quad(a, g, nwords, q, q < nQ, Q0, x, y, z, f);
+  // quirk Q1's source slice of the quad's slice: the 64 quads of a wave nearly always share a slice -- one look-up through
+  // scalar loads then (lane 0 always holds a quad) instead of one vector load per lane: this kernel is bound by those
+  int zp;
+  {
+    u32 unk;
+    const int zfirst = __builtin_amdgcn_readfirstlane(z);
+    if (__ballot(have && z != zfirst) == 0ull) zp = alias_of(a.occ, g, a.q1, zfirst, unk);
+    else zp = have ? alias_of(a.occ, g, a.q1, z, unk) : -1;
+  }
+  if (have) {
     u64 lid[4], o[NV];
-    quad_corners<MAP>(a, g, x, y, z, f, lid);
+    quad_corners<MAP>(a, g, x, y, z, f, zp, lid);
     finish_cell<TRI>(a, V0, totV, lid, o);
 #pragma unroll
     for (int i = 0; i < NV; i++) stage[wv][lane * NV + i] = o[i];

@@ -439,7 +439,8 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
 
 @pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"),
                                      ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",),
-                                     ("points_no_split", "proj_chunk=128"), ("cmap_linear",), ("proj_refill=64",), ("proj_refill=3", "proj_chunk=256")])
+                                     ("points_no_split", "proj_chunk=128"), ("cmap_linear",), ("proj_refill=64",), ("proj_refill=3", "proj_chunk=256"),
+                                     ("points_split=2", "classify_keep_tail"), ("points_split=4", "proj_chunk64_below=1")])
 def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, options):
     """When the dense corner map (4 B per lattice corner), the head tables or the vertex-word queue cannot be
     allocated the kernels recompute ids / search the prefix arrays instead; the sweep also runs without its staged
@@ -480,7 +481,9 @@ def test_count_forms_agree_with_oracle(pkg, oracle, extractor, shape):
     dev = torch.from_numpy(vox).cuda()
     a, b = 3, nz - 2
     try:
-        for form in (0, 1, 2):
+        # (1: the tile, in columns of 8 where those fill the chip -- not on volumes this small: one block per workgroup, like 2;
+        #  4 and 8: columns of that many blocks whatever their number)
+        for form in (0, 1, 2, 4, 8):
             extractor.debug_option("count_variant", form)
             assert_same_mesh(run_gpu(pkg, extractor, vol, 128, **kw), ref)
             # a slab: ghost slice below its owned range, halo above
