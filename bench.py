@@ -317,6 +317,24 @@ def main():
         torch.cuda.synchronize()
 
     res = None
+    fallback = None
+    if world > 1 and not args.host_offsets:
+        # the first step of the N>1 path on this node: should the one-wait step (device-resident rows, thin halo) raise on
+        # ANY rank, every rank learns of it here and all take the plain protocol (host in the loop, full halo) instead -- a
+        # slower curve is worth more than none.  (A hang cannot be caught: that is what the rehearsals are for.)
+        try:
+            res = sh.extract(buf, prm)
+            mine, why = 1, ""
+        except Exception as e:       # noqa: BLE001
+            mine, why = 0, "%s: %s" % (type(e).__name__, e)
+        okt = torch.tensor([mine], dtype=torch.int32, device="cpu" if rehearsal else device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            fallback = "one-wait step failed on some rank (%s): host-side offsets, full halo" % (why or "another rank")
+            args.host_offsets, args.full_halo, args.bits_first = True, True, False
+            ex.use_own_stream()
+            sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=False, device_offsets=False)
+            res = None
     for _ in range(args.warmup):
         res = sh.extract(buf, prm)
     partition = "uniform"
@@ -465,6 +483,8 @@ def main():
         out["roofline"]["note"] = ("largest kernel by time is the projection walk (%.0f %% of device time): f64 VALU-bound, "
                                    "neither an HBM nor an MFMA roofline applies to it" % (
                                        100.0 * stages["ms_project"] / stages["ms_total"]))
+        if fallback is not None:
+            out["fallback"] = fallback
         if single_check is not None:
             out["check_against_single"] = single_check
         if gather_ms is not None:
