@@ -508,7 +508,7 @@ int count_launch(cuberille_ctx *c, const Gate &gate) {
   HIP_TRY(c, launch_occupancy(c->pixel_type, c->w, c->g, c->tune, s));
   // (the LDS-tiled form pays where most words carry surface -- 2048^3 noise -- and costs where few do: it stages every
   //  row, a sparse block's untiled form skips whole words; the previous extraction's density decides)
-  const int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 1 : 0);
+  const int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 3 : 0);
   HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, tiled, s));
   if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   return CUBERILLE_OK;

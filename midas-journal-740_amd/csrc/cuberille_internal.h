@@ -130,8 +130,11 @@ struct Tuning {
   int points_variant = 3;     // 3 dense two-phase, 2 queue walk, 1 wave-window search, 0 block form
   int cmap_linear = 0;        // 0: the corner map in 4 x 4 x 2 bricks of one 128-byte line, 1: row-major as in round 2
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile (in columns of 8 blocks where slices are
-                              // whole blocks), 2: the tile, one block per workgroup, >= 4: columns of that many, 0: from memory,
-                              // -1: the tile when the previous extraction on the context found vertices in a quarter of its words
+                              // whole blocks), 2: the tile, one block per workgroup, 4 .. 31: columns of that many, 0: from memory,
+                              // 3 / 32 + one of those: the dense form (k_count_dense: one phase, corner logic per lattice corner,
+                              // pipelined columns) where rows are a power of two of whole words, else the tile as 1 / that,
+                              // -1: the dense form when the previous extraction on the context found vertices in a quarter of its
+                              //     words, else from memory
   // the walk: vertices per batch (0: 64 when the launch leaves wave slots empty, else 128), waves in the grid, idle lanes
   // at which a wave refills (0: 16; 64 = only when empty, where the previous extraction's walks took under four passes
   // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass

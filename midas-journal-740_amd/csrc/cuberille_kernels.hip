@@ -702,6 +702,219 @@ __device__ __forceinline__ void faces_word(const u64 *__restrict__ bits, const G
 }
 
 // ---------------------------------------------------------------------------------------------
+// The corner logic per LATTICE corner (the dense form of the count, k_count_dense).
+// Everything about the lattice corner (X, Y, Z) is a function of the 2x2x2 block of voxels around it; voxel x sees that
+// corner as its corner (0,dy,dz) when X = x and as its corner (1,dy,dz) when X = x + 1.  The per-voxel form above
+// evaluates the block once for each of the two (36 activation terms per word); here a word evaluates the four corner
+// rows (dy,dz) of the lattice positions X = 64k .. 64k+63 ONCE and reads both answers off them.  With b_E the inside bit
+// of block member E (code ex | ey<<1 | ez<<2: the voxel at X - ex, rows y+dy-ey, z+dz-ez; a larger code comes earlier in
+// raster order) and T_E = b_E & ~(b_E^1 & b_E^2 & b_E^4) "member E activates the corner" (it is inside and has a face
+// inside the block), D = (0,dy,dz):
+//   P(X) = T_D   & ~OR_{E>D}   T_E          voxel X     creates its corner D   = (0,dy,dz)
+//   R(X) = T_D+1 & ~OR_{E>D+1} T_E          voxel X - 1 creates its corner D+1 = (1,dy,dz)
+// Only voxels X - 1 and X are looked at: the rows `c` and the rows shifted up by one bit `m` (no x+1 rows).
+// Away from the image border the chains collapse.  "No member of H = {E >= k} activates" means every inside member of H
+// has its three neighbours inside; H is connected for k = 2 and k = 4 and every member of the block has a neighbour in
+// it, so either no member of H is inside or all eight are (and then nobody activates):
+//   D = 0:  P = b0 & ~(b1 | b2 | ... | b7)                   R = b1 & ~(b2 | ... | b7)
+//   D = 2:  P = b2 & ~(b3 | b4 | b5 | b6 | b7)               R = b3 & ~(b4 | b5 | b6 | b7)
+//   D = 4:  P = b4 & ~(b5|b6|b7)  |  b2..b7 & b1 & ~b0       R = b5 & ~(b6|b7)  |  b2..b7 & ~b1
+//   D = 6:  P = b6 & (~b7 | b5 & b3 & ~(b4 & b2))            R = b7 & ~(b6 & b5 & b3)
+// (all 256 blocks x 4 rows checked against the chains: tests/test_host.py) -- 23 three-input operations per 32 corners
+// instead of 72 for the 36 terms.  On the border of the image members that do not exist must not activate, and a
+// clamped copy of a row would: waves that touch a y or z border take the chains with the existence masks (lat_row_chain);
+// the two x borders are one bit per row each -- P at X = 0 (no voxel -1), R at X = nx (no voxel nx) -- and a pass of
+// their own over the block's rows (border_nibs) supplies them: no word evaluates them in passing.
+// What a word lacks besides is R(64k+64) for its voxel 63 -- bit 0 of the NEXT word's R, fetched from that word's lane
+// through LDS.
+// ---------------------------------------------------------------------------------------------
+template <int DY, int DZ, int E>
+__device__ __forceinline__ u64 lat_b(const u64 (&c)[3][3], const u64 (&m)[3][3]) {
+  return (E & 1) ? m[DZ - (E >> 2) + 1][DY - ((E >> 1) & 1) + 1] : c[DZ - (E >> 2) + 1][DY - ((E >> 1) & 1) + 1];
+}
+constexpr int TT_A_ANDN_BC = 0x10, TT_A_OR_B_ANDN_C = 0xf4, TT_AB_ANDN_C = 0x40, TT_A_AND_NB_OR_C = 0xb0;
+// interior corner rows: the closed forms
+template <int DY, int DZ>
+__device__ __forceinline__ void lat_row_closed(const u64 (&c)[3][3], const u64 (&m)[3][3], u64 &P, u64 &R) {
+  const u64 b0 = lat_b<DY, DZ, 0>(c, m), b1 = lat_b<DY, DZ, 1>(c, m), b2 = lat_b<DY, DZ, 2>(c, m), b3 = lat_b<DY, DZ, 3>(c, m),
+            b4 = lat_b<DY, DZ, 4>(c, m), b5 = lat_b<DY, DZ, 5>(c, m), b6 = lat_b<DY, DZ, 6>(c, m), b7 = lat_b<DY, DZ, 7>(c, m);
+  constexpr int D = (DY << 1) | (DZ << 2);
+  if constexpr (D == 0) {
+    const u64 z = bop3<TT_OR3>(b2, b3, b4) | bop3<TT_OR3>(b5, b6, b7);
+    R = b1 & ~z;
+    P = bop3<TT_A_ANDN_BC>(b0, b1, z);
+  } else if constexpr (D == 2) {
+    const u64 x = bop3<TT_OR3>(b4, b5, b6);
+    R = bop3<TT_A_ANDN_BC>(b3, x, b7);
+    P = bop3<TT_A_ANDN_BC>(b2, b3, x | b7);
+  } else if constexpr (D == 4) {
+    const u64 w = bop3<TT_AND3>(b2, b3, b4) & bop3<TT_AND3>(b5, b6, b7);
+    R = bop3<TT_A_OR_B_ANDN_C>(bop3<TT_A_ANDN_BC>(b5, b6, b7), w, b1);
+    P = (b4 & ~bop3<TT_OR3>(b5, b6, b7)) | bop3<TT_AB_ANDN_C>(w, b1, b0);
+  } else {
+    R = b7 & ~bop3<TT_AND3>(b6, b5, b3);
+    P = bop3<TT_A_AND_NB_OR_C>(b6, b7, bop3<TT_AB_ANDN_C>(b5, b3, b4 & b2));
+  }
+}
+// the chains, with the existence of every member: T_E ...
+template <int DY, int DZ, int E>
+__device__ __forceinline__ u64 lat_T(const u64 (&c)[3][3], const u64 (&m)[3][3], const u32 (&exy)[3], const u32 (&exz)[3]) {
+  constexpr int sy = DY - ((E >> 1) & 1), sz = DZ - (E >> 2);                 // the member's row
+  const u64 t = bop3<TT_AND3>(lat_b<DY, DZ, E ^ 1>(c, m), lat_b<DY, DZ, E ^ 2>(c, m), lat_b<DY, DZ, E ^ 4>(c, m));
+  const u64 mem = lat_b<DY, DZ, E>(c, m);
+  u64 a = bop3<TT_A_ANDN_B>(mem, t, t);
+  if (sy != 0 || sz != 0) {
+    const u32 e = exy[sy + 1] & exz[sz + 1];
+    a &= (u64)e | ((u64)e << 32);
+  }
+  return a;
+}
+// ... their OR over E = E0, E0+2, ... <= 7 (one parity of x: the members at X for even E, at X-1 for odd E) ...
+template <int DY, int DZ, int E0>
+__device__ __forceinline__ u64 lat_or(const u64 (&c)[3][3], const u64 (&m)[3][3], const u32 (&exy)[3], const u32 (&exz)[3]) {
+  if constexpr (E0 > 7) return 0ull;
+  else if constexpr (E0 + 2 > 7) return lat_T<DY, DZ, E0>(c, m, exy, exz);
+  else if constexpr (E0 + 4 > 7) return lat_T<DY, DZ, E0>(c, m, exy, exz) | lat_T<DY, DZ, E0 + 2>(c, m, exy, exz);
+  else return bop3<TT_OR3>(lat_T<DY, DZ, E0>(c, m, exy, exz), lat_T<DY, DZ, E0 + 2>(c, m, exy, exz), lat_or<DY, DZ, E0 + 4>(c, m, exy, exz));
+}
+// ... and P and R of one corner row (every voxel X and X - 1 taken to exist: the x borders are not evaluated here)
+template <int DY, int DZ>
+__device__ __forceinline__ void lat_row_chain(const u64 (&c)[3][3], const u64 (&m)[3][3], const u32 (&exy)[3], const u32 (&exz)[3], u64 &P, u64 &R) {
+  constexpr int D = (DY << 1) | (DZ << 2);
+  const u64 s = lat_or<DY, DZ, D + 3>(c, m, exy, exz) | lat_or<DY, DZ, D + 2>(c, m, exy, exz);
+  const u64 t1 = lat_T<DY, DZ, D + 1>(c, m, exy, exz);
+  const u64 t0 = lat_T<DY, DZ, D>(c, m, exy, exz);
+  P = bop3<TT_A_ANDN_BC>(t0, t1, s);
+  R = t1 & ~s;
+}
+
+// Where a word of the dense count reads its rows: the staged copy of the bit rows (k_count_dense), word index `idx`,
+// rows W words apart, the copies of the slices below / above `below` / `above` words away
+struct DenseAt {
+  const u64 *tile;
+  int idx, W, below, above;
+  int k, y, z;
+};
+
+// One word of the dense count: its quads and the vertices its voxels create as V | Q<<16 -- all but the (at most four)
+// that voxel 63 creates at the lattice corners X = 64k+64 and, in a row's first word, those that voxel 0 creates at
+// X = 0 -- and `nibs`: how many of the four corner rows have R set at X = 64k, i.e. the vertices the word BEFORE this one
+// lacks (already taken off this word's count: bit 0 of R is that word's voxel 63).
+// YZ: the chains with the existence masks (waves on a y or z border); zp: quirk Q1's source slice (or -1).
+template <bool YZ, bool NOCORNER = false>
+__device__ __forceinline__ void lattice_word(const DenseAt &w, const u64 *__restrict__ bits, const Grid &g, int zp, u32 &packed, u32 &nibs) {
+  u64 c[3][3], m[3][3];
+  u32 exy[3] = {~0u, ~0u, ~0u}, exz[3] = {~0u, ~0u, ~0u};
+  int yo[3] = {-w.W, 0, w.W}, zo[3] = {w.below, 0, w.above};
+  if (YZ) {
+    if (w.y == 0) { exy[0] = 0u; yo[0] = 0; }
+    if (w.y == g.ny - 1) { exy[2] = 0u; yo[2] = 0; }
+    if (w.z == 0) { exz[0] = 0u; zo[0] = 0; }
+    if (w.z == g.nzb - 1) { exz[2] = 0u; zo[2] = 0; }
+  }
+  const bool first = w.k == 0;
+#pragma unroll
+  for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      const int off = w.idx + yo[dy] + zo[dz];
+      // the word and the word before it (one two-word LDS read).  Before a row's first word that is the last word of the
+      // row before: bit 0 of `m` is then meaningless, and so is bit 0 of P and R -- which the x-border pass supplies
+      const u64 cc = w.tile[off], pw = w.tile[off - 1];
+      const u32 lo = (u32)cc, hi = (u32)(cc >> 32);
+      c[dz][dy] = cc;
+      m[dz][dy] = (u64)__builtin_amdgcn_alignbit(lo, (u32)(pw >> 32), 31) | ((u64)__builtin_amdgcn_alignbit(hi, lo, 31) << 32);
+    }
+  const u64 I = c[1][1];
+  u64 P[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+  if (!NOCORNER) {
+    // every P is a subset of voxel X's own bits (it is member D of each corner row): without bit 0 of a first word there
+    // (R's bit 0 stays meaningless there: nobody reads a first word's `nibs`)
+    c[1][1] = first ? (I & ~1ull) : I;
+    if (YZ) {
+      lat_row_chain<0, 0>(c, m, exy, exz, P[0], R[0]);
+      lat_row_chain<1, 0>(c, m, exy, exz, P[1], R[1]);
+      lat_row_chain<0, 1>(c, m, exy, exz, P[2], R[2]);
+      lat_row_chain<1, 1>(c, m, exy, exz, P[3], R[3]);
+    } else {
+      lat_row_closed<0, 0>(c, m, P[0], R[0]);
+      lat_row_closed<1, 0>(c, m, P[1], R[1]);
+      lat_row_closed<0, 1>(c, m, P[2], R[2]);
+      lat_row_closed<1, 1>(c, m, P[3], R[3]);
+    }
+  }
+  if (zp >= 0) {
+    // quirk Q1: a bottom corner (dz = 0) that exists as a top-plane corner of the aliased source slice zp -- an existing
+    // inside voxel of that slice touches the lattice corner (X, y+dy) -- is looked up, not created
+    const u64 *src = bits + ((size_t)zp * g.ny + w.y) * g.W + w.k;
+    u64 any[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      const u64 *r = src + yo[dy];
+      const u64 cc = r[0];
+      any[dy] = (cc | (cc << 1) | (first ? 0ull : (r[-1] >> 63))) & ((u64)exy[dy] | ((u64)exy[dy] << 32));
+    }
+    const u64 L0 = any[0] | any[1], L1 = any[1] | any[2];
+    P[0] &= ~L0; R[0] &= ~L0; P[1] &= ~L1; R[1] &= ~L1;
+  }
+  nibs = ((u32)R[0] & 1u) + ((u32)R[1] & 1u) + ((u32)R[2] & 1u) + ((u32)R[3] & 1u);
+  const u64 nw = w.tile[w.idx + (w.k < w.W - 1 ? 1 : 0)];
+  const u64 p11 = (I >> 1) | (w.k < w.W - 1 ? (nw << 63) : (I & (1ull << 63)));
+  // (at X = 0 the face test reads the clamped neighbour: voxel 0 itself)
+  const u64 m11 = first ? (m[1][1] | 1ull) : m[1][1];
+  const int nQ = popc64(I & ~m11) + popc64(I & ~c[1][0]) + popc64(I & ~p11) + popc64(I & ~c[1][2]) + popc64(I & ~c[0][1]) + popc64(I & ~c[2][1]);
+  // (a member that activates has a face: no mask is "and"ed with the word's faces)
+  int nV = -(int)nibs;
+#pragma unroll
+  for (int r = 0; r < 4; r++) nV += popc64(P[r]) + popc64(R[r]);
+  packed = (u32)nV | ((u32)nQ << 16);
+}
+
+// The two x borders of a row, one bit per corner row each: the corners X = 0 of voxel 0 (AT_START: no voxel -1 exists,
+// the answer is P) and the corners X = nx of voxel nx-1 (the answer is R; no voxel nx).  Only one parity of the block is
+// left, a 2x2 block in (y, z) with members e = ey | ez<<1: T_e = b_e & ~(b_e^1 & b_e^2) -- the missing x neighbour is the
+// clamped voxel itself -- and corner row d = dy | dz<<1 is created by the row's own voxel, member d, when T_d & ~OR_{e>d} T_e.
+// lo: the first word of the row in the staged rows (AT_START) or its last one; returns how many of the four are set.
+template <bool AT_START>
+__device__ __forceinline__ u32 border_nibs(const DenseAt &w, const u64 *__restrict__ bits, const Grid &g, int zp) {
+  const u32 *t32 = reinterpret_cast<const u32 *>(w.tile) + (AT_START ? 0 : 1);     // bit 0 of the low dword / bit 31 of the high one
+  u32 exy[3] = {~0u, ~0u, ~0u}, exz[3] = {~0u, ~0u, ~0u};
+  int yo[3] = {-w.W, 0, w.W}, zo[3] = {w.below, 0, w.above};
+  if (w.y == 0) { exy[0] = 0u; yo[0] = 0; }
+  if (w.y == g.ny - 1) { exy[2] = 0u; yo[2] = 0; }
+  if (w.z == 0) { exz[0] = 0u; zo[0] = 0; }
+  if (w.z == g.nzb - 1) { exz[2] = 0u; zo[2] = 0; }
+  u32 b[3][3];
+#pragma unroll
+  for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) b[dz][dy] = t32[2 * (w.idx + yo[dy] + zo[dz])];
+  u32 created[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const int dy = d & 1, dz = d >> 1;
+    u32 earlier = 0u, own = 0u;
+#pragma unroll
+    for (int e = 3; e >= d; e--) {
+      const int sy = dy - (e & 1), sz = dz - (e >> 1);              // the member's row; its neighbours: the other y, the other z
+      const u32 t = b[sz + 1][sy + 1] & ~(b[sz + 1][dy - ((e ^ 1) & 1) + 1] & b[dz - ((e ^ 2) >> 1) + 1][sy + 1]) & exy[sy + 1] & exz[sz + 1];
+      if (e > d) earlier |= t;
+      else own = t;
+    }
+    created[d] = own & ~earlier;
+  }
+  if (zp >= 0) {
+    // quirk Q1 (see lattice_word): the aliased source slice's voxels at x = 0 / x = nx-1 of rows y-1, y, y+1
+    const u32 *s32 = reinterpret_cast<const u32 *>(bits + ((size_t)zp * g.ny + w.y) * g.W + w.k) + (AT_START ? 0 : 1);
+    const u32 a0 = s32[2 * yo[0]] & exy[0], a1 = s32[0], a2 = s32[2 * yo[2]] & exy[2];
+    created[0] &= ~(a0 | a1);
+    created[1] &= ~(a1 | a2);
+  }
+  const u32 any4 = AT_START ? 0u : 31u;
+  return ((created[0] >> any4) & 1u) + ((created[1] >> any4) & 1u) + ((created[2] >> any4) & 1u) + ((created[3] >> any4) & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: count + scan.  A block owns COUNT_WB consecutive words of the flat raster order (32 scan segments).
 //   phase 1  every word: the six face masks (7 bit-rows) -> quad count; words with a face are
 //            queued in LDS (a voxel only creates corners on faces it emits, so words without a
@@ -769,15 +982,27 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       const long long rowLast = (long long)z1 * g.ny + y1;
       const int len = (int)(rowLast - rowFirst + 3) * g.W;    // the block's rows, one before, one after
       const long long nbuf = (long long)g.nzb * g.ny * g.W;
+      // (every load of a thread in flight at once -- addresses clamped into the buffer, nothing conditional -- then the LDS
+      //  writes: as a loop of load, wait, write the copy was 13 dependent round trips to memory per block, a third of the
+      //  kernel's time on a dense field)
+      constexpr int TL = (TILE_PLANE + NT - 1) / NT;
       if (it == 0) {
+        u64 v[3][TL];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
           const long long gstart = (rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W;
-          for (int j = tid; j < len; j += NT) {
-            const long long gidx = gstart + j;
-            tile[p * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;   // (rows off the buffer are never read)
+#pragma unroll
+          for (int u = 0; u < TL; u++) {
+            long long gidx = gstart + tid + u * NT;
+            gidx = gidx < 0 ? 0 : (gidx >= nbuf ? nbuf - 1 : gidx);      // (rows off the buffer are never read)
+            v[p][u] = bits[gidx];
           }
         }
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+          for (int u = 0; u < TL; u++)
+            if (tid + u * NT < len) tile[p * TILE_PLANE + tid + u * NT] = v[p][u];
       } else {
         // the planes roll: the slice above the previous block is this block's own, the new slice above takes the place of
         // the one that was below (every thread is past its last read of it: the barrier behind phase 2).  (Loading it a
@@ -785,10 +1010,16 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
         slot = (it + 1) % 3;
         const int fresh = (it + 2) % 3;
         const long long gstart = (rowFirst - 1 + (long long)g.ny) * g.W;
-        for (int j = tid; j < len; j += NT) {
-          const long long gidx = gstart + j;
-          tile[fresh * TILE_PLANE + j] = (gidx >= 0 && gidx < nbuf) ? bits[gidx] : 0ull;
+        u64 v[TL];
+#pragma unroll
+        for (int u = 0; u < TL; u++) {
+          long long gidx = gstart + tid + u * NT;
+          gidx = gidx < 0 ? 0 : (gidx >= nbuf ? nbuf - 1 : gidx);
+          v[u] = bits[gidx];
         }
+#pragma unroll
+        for (int u = 0; u < TL; u++)
+          if (tid + u * NT < len) tile[fresh * TILE_PLANE + tid + u * NT] = v[u];
       }
     }
     __syncthreads();
@@ -889,6 +1120,210 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       }
     }
   }   // the workgroup's next block
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2, the DENSE form (a surface that touches most words; rows of whole words, a power of two of them, so that a row never
+// straddles two blocks).  Same outputs as k_count, another shape:
+//   * ONE phase instead of two: every word of the block, in raster order, takes its faces and its corner logic from the
+//     same nine staged rows, the corner logic per lattice corner (lattice_word: the closed forms, no x+1 rows, no queue of
+//     surface words, no data-dependent loads); the vertices a word's voxel 63 creates at the corners one past the word are
+//     the next word's four `nib` bits, fetched through LDS; the x borders of the rows are a short pass of their own;
+//   * the counts stay in registers between that phase and the scan (thread t owns words t, t+512, ... = lane `lane` of
+//     segments wv, wv+8, ...);
+//   * a workgroup walks up its column of blocks with the memory round trips of a block taken off its path: the plane
+//     the NEXT block adds is loaded into registers before this block's words are looked at and written to LDS behind them
+//     (a block's time was a third copy, and the copy pure latency); the returning atomic that reserves the block's
+//     stretch of the vertex-word queue is waited for one block later, and the queue is written then;
+//   * two barriers per block instead of five.
+// zrun <= 1: one block per workgroup (slices that are not whole blocks, thin slabs): the same code without the roll.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>    // MODE 0 in the library; microbench: 4 no corner logic, 8 no x-border pass
+__global__ __launch_bounds__(512, 4) void k_count_dense(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g, size_t nwords,
+                                                       int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
+                                                       u64 *__restrict__ blockTot, u32 *__restrict__ vqueue, Totals *__restrict__ tot,
+                                                       int zrun) {
+  constexpr int NT = 512, NWAVES = NT / 64, NSEG = COUNT_WB / 64, PER = COUNT_WB / NT, TL = (TILE_PLANE + NT - 1) / NT;
+  __shared__ u64 tileStore[3 * TILE_PLANE + 1];
+  u64 *const tile = tileStore + 1;       // (the word before the first word of the staged rows is read -- and not looked at)
+  __shared__ unsigned char seam[COUNT_WB], seamV[COUNT_WB], seamF[COUNT_WB];   // lattice_word's `nibs` of every word; border_nibs behind a row / at its start
+  __shared__ u64 segTot[NSEG];
+  __shared__ u64 segVW[2][NSEG];         // per segment: which of its 64 words create vertices (this block's, the one before's)
+  __shared__ u32 segVWPre[2][NSEG];      // ... and how many such words the block's earlier segments hold
+  __shared__ u32 vbaseS[2];
+  __shared__ u32 g0InSeg;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;   // first owned word (0: no ghost slice)
+  if (zrun < 1) zrun = 1;
+  const u32 bps = zrun > 1 ? (u32)(((size_t)g.ny * g.W) >> COUNT_LG) : 1u;        // count blocks per slice
+  const u32 colBlock = zrun > 1 ? blockIdx.x % bps : 0u, colRun = zrun > 1 ? blockIdx.x / bps : 0u;
+  auto block_of = [&](int it) -> u32 { return zrun > 1 ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x; };
+  int nsteps = 0;
+  while (nsteps < zrun && (size_t)block_of(nsteps) * COUNT_WB < nwords) nsteps++;
+  if (tid == 0) g0InSeg = 0;
+  const long long nbuf = (long long)g.nzb * g.ny * g.W;
+  // geometry of a block's staged rows: its own rows, one before, one after (the same of the slices below and above)
+  auto rows_of = [&](size_t w0, long long &rowFirst, int &len, int &zFirst, int &zLast) {
+    int k0, y0, z0, k1, y1, z1;
+    word_coords(g, w0, k0, y0, z0);
+    const size_t wl = w0 + COUNT_WB - 1 < nwords ? w0 + COUNT_WB - 1 : nwords - 1;
+    word_coords(g, wl, k1, y1, z1);
+    rowFirst = (long long)z0 * g.ny + y0;
+    len = (int)((long long)z1 * g.ny + y1 - rowFirst + 3) * g.W;
+    zFirst = z0; zLast = z1;
+  };
+  auto load_plane = [&](long long gstart, u64 (&v)[TL]) {
+#pragma unroll
+    for (int u = 0; u < TL; u++) {
+      long long gidx = gstart + tid + u * NT;
+      gidx = gidx < 0 ? 0 : (gidx >= nbuf ? nbuf - 1 : gidx);      // (rows off the buffer are never read)
+      v[u] = bits[gidx];
+    }
+  };
+  auto store_plane = [&](int p, int len, const u64 (&v)[TL]) {
+#pragma unroll
+    for (int u = 0; u < TL; u++)
+      if (tid + u * NT < len) tile[p * TILE_PLANE + tid + u * NT] = v[u];
+  };
+  if (nsteps == 0) return;
+  {
+    long long rowFirst; int len, za, zb;
+    rows_of((size_t)block_of(0) * COUNT_WB, rowFirst, len, za, zb);
+    u64 v[3][TL];
+#pragma unroll
+    for (int p = 0; p < 3; p++) load_plane((rowFirst - 1 + (long long)(p - 1) * g.ny) * g.W, v[p]);
+#pragma unroll
+    for (int p = 0; p < 3; p++) store_plane(p, len, v[p]);
+  }
+  __syncthreads();
+  u32 errBits = 0, pendingBase = 0;
+  // the queue stretch of block `it`: reserved by wave 1 behind that block's scan, written a block later
+  auto flush_queue = [&](int it) {
+    const int b = it & 1;
+    const size_t w0 = (size_t)block_of(it) * COUNT_WB;
+    const u32 base = vbaseS[b];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int sg = wv + NWAVES * j;
+      const u64 vm = segVW[b][sg];
+      if ((vm >> lane) & 1ull) vqueue[base + segVWPre[b][sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
+    }
+  };
+  for (int it = 0; it < nsteps; it++) {
+    const u32 blk = block_of(it);
+    const size_t w0 = (size_t)blk * COUNT_WB;
+    const int cur = it & 1;
+    long long rowFirst; int len, zFirst, zLast;
+    rows_of(w0, rowFirst, len, zFirst, zLast);
+    const int slot = (it + 1) % 3;                       // which third of the tile holds the block's own slice
+    const bool more = it + 1 < nsteps;
+    u64 pv[TL];
+    if (more) load_plane((rowFirst - 1 + 2ll * g.ny) * g.W, pv);     // the slice above the NEXT block (same rows, one slice up)
+    // word i of the block sits at tile[own + W + i]: the staged rows are the block's rows behind one row more
+    DenseAt da;
+    da.tile = tile; da.W = g.W;
+    da.below = ((slot + 2) % 3 - slot) * TILE_PLANE; da.above = ((slot + 1) % 3 - slot) * TILE_PLANE;
+    const int own = slot * TILE_PLANE + g.W;
+    // quirk Q1's source slice: one look-up per block where the block lies in one slice (the usual case)
+    u32 unknownBlk = 0;
+    const int zpBlk = zFirst == zLast ? alias_of(occ, g, q1, zFirst, unknownBlk) : -1;
+    // the two x borders of every row of the block: the corners X = nx of its last word's voxel 63 (first half of the
+    // items), the corners X = 0 of its first word's voxel 0 (second half)
+    // (ahead of the words, a share for every wave: behind them two waves would walk these few dependent LDS reads alone
+    //  while six wait at the barrier)
+    const int lgRows = COUNT_LG - g.wShift, nrows = (MODE & 8) ? 0 : 1 << lgRows, share = (2 * nrows + NWAVES - 1) / NWAVES;
+    for (int u = lane; u < share; u += 64) {
+      const int t = wv * share + u;
+      if (t >= 2 * nrows) break;
+      const int v = t & (nrows - 1);
+      const bool atStart = (t >> lgRows) != 0;
+      const size_t gi = w0 + ((size_t)v << g.wShift);
+      u32 nibs = 0;
+      if (gi < nwords) {
+        word_coords(g, gi, da.k, da.y, da.z);
+        u32 unknown;
+        const int zp = zFirst == zLast ? zpBlk : alias_of(occ, g, q1, da.z, unknown);
+        da.idx = own + (v << g.wShift);
+        if (atStart) {
+          if (tile[da.idx] & 1ull) nibs = border_nibs<true>(da, bits, g, zp);
+        } else {
+          da.idx += g.W - 1; da.k = g.W - 1;
+          if (tile[da.idx] >> 63) nibs = border_nibs<false>(da, bits, g, zp);
+        }
+      }
+      if (atStart) seamF[v] = (unsigned char)nibs;
+      else seamV[v] = (unsigned char)nibs;
+    }
+    u32 pk[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int i = tid + NT * j;
+      const size_t gi = w0 + i;
+      u32 packed = 0, nibs = 0;
+      if (gi < nwords) {
+        word_coords(g, gi, da.k, da.y, da.z);
+        da.idx = own + i;
+        // nothing inside the word and nothing in the voxel before it: no face, no vertex, nothing the word before lacks
+        const bool live = tile[da.idx] != 0ull || (da.k > 0 && (tile[da.idx - 1] >> 63));
+        u32 unknown = unknownBlk;
+        const int zp = zFirst == zLast ? zpBlk : (live ? alias_of(occ, g, q1, da.z, unknown) : -1);
+        if (live) errBits |= unknown;
+        const bool yzBorder = da.y == 0 || da.y == g.ny - 1 || da.z == 0 || da.z == g.nzb - 1;
+        if (__ballot(yzBorder && live) != 0ull) { if (live) lattice_word<true, (MODE & 4) != 0>(da, bits, g, zp, packed, nibs); }
+        else if (live) lattice_word<false, (MODE & 4) != 0>(da, bits, g, zp, packed, nibs);
+      }
+      pk[j] = packed;
+      seam[i] = (unsigned char)nibs;
+    }
+    if (vqueue && it > 0 && tid == 64) vbaseS[cur ^ 1] = pendingBase;       // (the atomic of the block before has long returned)
+    __syncthreads();                                                        // ---- A: every read of the staged rows is done
+    if (more) store_plane(it % 3, len, pv);                                 // the plane that was below this block: no longer needed
+    if (vqueue && it > 0) flush_queue(it - 1);
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int sg = wv + NWAVES * j, i = sg * 64 + lane, k = i & (g.W - 1);
+      const size_t gi = w0 + i;
+      // the vertices voxel 63 creates at the corners one past the word -- the next word's four bits, or those of the place
+      // behind the row -- and in a row's first word those of voxel 0 at X = 0
+      u32 packed = pk[j] + (k == g.W - 1 ? (u32)seamV[i >> g.wShift] : (u32)seam[(i + 1) & (COUNT_WB - 1)]);
+      if (k == 0) packed += (u32)seamF[i >> g.wShift];
+      const u32 incl = wave_inclusive_sum(packed);
+      if (gi < nwords) prefix[gi] = incl - packed;
+      if (gi == g0) g0InSeg = incl - packed;
+      if (lane == 63) segTot[sg] = (u64)(incl & 0xffffu) | ((u64)(incl >> 16) << 32);
+      // words that create vertices go to the global vertex-word queue IN ORDER (see k_count)
+      const u64 vm = __ballot((packed & 0xffffu) != 0u);
+      if (lane == 0) segVW[cur][sg] = vm;
+    }
+    __syncthreads();                                                        // ---- B: segment totals, the next block's plane
+    if (wv == 0) {
+      // the block's 32 segments: exclusive scan of their totals -> segPre; block total -> blockTot
+      const u64 t = lane < NSEG ? segTot[lane] : 0ull;
+      const u64 incl = wave_inclusive_sum2(t);
+      const u64 excl = incl - t;                                   // both halves stay below 2^21: no borrow crosses
+      const size_t seg = (w0 >> 6) + lane;
+      if (lane < NSEG && (seg << 6) < nwords) segPre[seg] = excl;
+      if (g0 > 0 && (g0 >> COUNT_LG) == blk && lane == (int)((g0 >> 6) & (NSEG - 1))) {
+        const u32 in = g0InSeg;
+        tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
+      }
+      if (lane == NSEG - 1) blockTot[blk] = incl;
+    } else if (wv == 1 && vqueue) {
+      // 32 segment counts -> exclusive prefix, one global atomic per block (its answer is read a block later)
+      const u32 n = lane < NSEG ? (u32)__popcll(segVW[cur][lane]) : 0u;
+      const u32 incl = wave_inclusive_sum(n);
+      if (lane < NSEG) segVWPre[cur][lane] = incl - n;
+      const u32 total = __shfl(incl, 63, 64);
+      pendingBase = 0;
+      if (lane == 0 && total) pendingBase = atomicAdd(&tot->nVertexWords, total);
+    }
+  }
+  if (errBits) atomicOr(&tot->err, errBits);
+  if (vqueue) {
+    if (tid == 64) vbaseS[(nsteps - 1) & 1] = pendingBase;
+    __syncthreads();
+    flush_queue(nsteps - 1);
+  }
 }
 
 // Exclusive scan of the count blocks' totals (V | Q<<32 each) -> blockBase[2b], [2b+1] and the grand totals.  One
@@ -2429,6 +2864,11 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
   const size_t sliceWords = (size_t)g.ny * g.W;
+  // (tiled 3, or 32 + one of the values below: the dense form -- faces and corner logic in one phase, per lattice corner --
+  //  where rows are whole words and a power of two of them, else the two-phase tile)
+  const bool fused = (tiled == 3 || tiled >= 32) && g.wShift >= 0 && g.lastpos == 63;
+  if (tiled == 3) tiled = 1;
+  else if (tiled >= 32) tiled -= 32;
   if (tiled && g.W <= TILE_WMAX) {
     // (slices that are whole count blocks: a workgroup walks up a column of COUNT_ZRUN blocks and re-uses two of its three planes)
     const int want = tiled == 1 ? COUNT_ZRUN : tiled >= 4 ? tiled : 0;      // (tiled 2: one block per workgroup; >= 4: that run)
@@ -2437,8 +2877,12 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
     const bool columnsFill = want && (u64)(sliceWords / COUNT_WB) * (u64)((g.oz1 - g.cz0 + want - 1) / want) >= 1024;
     const int zrun = want && sliceWords % COUNT_WB == 0 && g.oz1 - g.cz0 >= 2 * want && (columnsFill || tiled >= 4) ? want : 0;
     const unsigned grid = zrun ? (unsigned)(sliceWords / COUNT_WB) * (unsigned)((g.oz1 - g.cz0 + zrun - 1) / zrun) : blocks;
-    hipLaunchKernelGGL((k_count<0, true, 512>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals, zrun);
+    if (fused)
+      hipLaunchKernelGGL((k_count_dense<0>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre, w.blockTot, vq,
+                         w.totals, zrun);
+    else
+      hipLaunchKernelGGL((k_count<0, true, 512>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                         w.blockTot, vq, w.totals, zrun);
   } else if (blocks <= 64)
     // (a handful of blocks -- every volume the reference ships: the kernel's time is a block's latency, two trips through its
     //  loops instead of eight)

@@ -82,6 +82,20 @@ int main(int argc, char **argv) {
   timeIt([&] { KC(0, true, 512, w.vqueue); }, "tiled 512: everything");
   timeIt([&] { KC(4, true, 512, w.vqueue); }, "tiled 512: no corner logic");
   timeIt([&] { KC(6, true, 512, w.vqueue); }, "tiled 512: tile + faces + wave scans + prefix stores only");
+#define KF(MODE, ZRUN) hipLaunchKernelGGL((k_count_dense<MODE>), dim3(blocks), dim3(512), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
+                                                    w.prefix, w.segPre, w.blockTot, w.vqueue, w.totals, ZRUN)
+#define KT(MODE, ZRUN) hipLaunchKernelGGL((k_count<MODE, true, 512>), dim3(blocks), dim3(512), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
+                                                    w.prefix, w.segPre, w.blockTot, w.vqueue, w.totals, ZRUN)
+  timeIt([&] { KF(0, 0); }, "dense form: everything");
+  timeIt([&] { KF(8, 0); }, "dense form: no virtual words");
+  timeIt([&] { KF(4, 0); }, "dense form: no corner logic");
+  timeIt([&] { KF(12, 0); }, "dense form: no corner logic, no virtual words");
+    if (((size_t)n * g.W) % COUNT_WB == 0) {
+    timeIt([&] { KT(0, 8); }, "tiled 512 in columns of 8: everything");
+    timeIt([&] { KF(0, 8); }, "dense form in columns of 8: everything");
+    timeIt([&] { KF(8, 8); }, "dense form in columns of 8: no virtual words");
+    timeIt([&] { KF(12, 8); }, "dense form in columns of 8: no corner logic, no virtual words");
+  }
   timeIt([&] { KC(0, true, 256, w.vqueue); }, "tiled 256: everything");
   timeIt([&] { KC(0, true, 1024, w.vqueue); }, "tiled 1024: everything");
   return 0;

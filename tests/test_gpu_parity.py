@@ -483,7 +483,9 @@ def test_count_forms_agree_with_oracle(pkg, oracle, extractor, shape):
     try:
         # (1: the tile, in columns of 8 where those fill the chip -- not on volumes this small: one block per workgroup, like 2;
         #  4 and 8: columns of that many blocks whatever their number)
-        for form in (0, 1, 2, 4, 8):
+        # (3, 32 + form: the dense form of the tile -- one phase, the corner logic per lattice corner -- where rows are a power of
+        #  two of whole words: the first two shapes; the third takes the two-phase tile)
+        for form in (0, 1, 2, 4, 8, 3, 34, 36, 40):
             extractor.debug_option("count_variant", form)
             assert_same_mesh(run_gpu(pkg, extractor, vol, 128, **kw), ref)
             # a slab: ghost slice below its owned range, halo above

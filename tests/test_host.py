@@ -372,3 +372,39 @@ def test_bulk_mesh_fill_under_sanitizers():
     subprocess.check_call(["make", "-s", "-C", itk, "build/mesh_fill_asan"])
     r = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "mesh fill ok" in r.stdout, (r.stdout[-300:], r.stderr[-2000:])
+
+
+def test_lattice_corner_closed_forms_equal_the_activation_chains():
+    """The dense form of the count kernel (csrc/cuberille_kernels.hip: lat_row_closed) reads "voxel X / voxel X-1 creates
+    this lattice corner" off closed forms over the eight inside bits of the 2x2x2 block around the corner; the per-voxel
+    form and the border waves evaluate the chains of activation terms they were derived from (SURVEY.md section 8a items
+    2-3; txx:164-194: the first voxel in raster order that has a face at the corner creates it).  All 256 blocks x the four
+    corner rows, away from the image border."""
+    import itertools
+
+    def T(b, e):        # member e is inside and one of its three neighbours inside the block is not
+        return b[e] & (1 - (b[e ^ 1] & b[e ^ 2] & b[e ^ 4]))
+
+    def chains(b, d):   # a larger member code comes earlier in raster order
+        s = 0
+        for e in range(d + 2, 8):
+            s |= T(b, e)
+        return T(b, d) & (1 - (T(b, d + 1) | s)), T(b, d + 1) & (1 - s)
+
+    def closed(b, d):
+        b0, b1, b2, b3, b4, b5, b6, b7 = b
+        n = lambda v: 1 - v     # noqa: E731
+        if d == 0:
+            z = b2 | b3 | b4 | b5 | b6 | b7
+            return b0 & n(b1 | z), b1 & n(z)
+        if d == 2:
+            o = b4 | b5 | b6 | b7
+            return b2 & n(b3 | o), b3 & n(o)
+        if d == 4:
+            w = b2 & b3 & b4 & b5 & b6 & b7
+            return (b4 & n(b5 | b6 | b7)) | (w & b1 & n(b0)), (b5 & n(b6 | b7)) | (w & n(b1))
+        return b6 & (n(b7) | (b5 & b3 & n(b4 & b2))), b7 & n(b6 & b5 & b3)
+
+    for b in itertools.product((0, 1), repeat=8):
+        for d in (0, 2, 4, 6):
+            assert chains(b, d) == closed(b, d), (b, d)
