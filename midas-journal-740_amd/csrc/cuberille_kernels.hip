@@ -890,6 +890,15 @@ __device__ __forceinline__ u32 border_nibs(const DenseAt &w, const u64 *__restri
 #pragma unroll
     for (int dy = 0; dy < 3; dy++) b[dz][dy] = t32[2 * (w.idx + yo[dy] + zo[dz])];
   u32 created[4];
+  if (__ballot(w.y == 0 || w.y == g.ny - 1 || w.z == 0 || w.z == g.nzb - 1) == 0ull) {
+    // away from the y / z borders the 2D chains collapse like the blocks' (member d of corner row d is the row's own voxel):
+    //   d = 0: b0 & ~(b1|b2|b3)    d = 1: b1 & ~(b2|b3)    d = 2: b2 & (~b3 | b1 & ~b0)    d = 3: b3 & ~(b2 & b1)
+    // with b_e = b[dz - ez + 1][dy - ey + 1]
+    created[0] = b[1][1] & ~(b[1][0] | b[0][1] | b[0][0]);
+    created[1] = b[1][1] & ~(b[0][2] | b[0][1]);
+    created[2] = b[1][1] & (~b[1][0] | (b[2][0] & ~b[2][1]));
+    created[3] = b[1][1] & ~(b[1][2] & b[2][1]);
+  } else
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     const int dy = d & 1, dz = d >> 1;
