@@ -166,6 +166,29 @@ def series_probe(pkg, torch, ex, buf, desc, prm, device_index, volumes=20):
         ex2.close()
 
 
+def first_calls_probe(pkg, torch, buf, desc, prm, device_index, calls=4):
+    """The first extractions on a FRESH context (set up, as the drop-in filter's constructor does it: cuberille_warm_up): the
+    launch shapes of an extraction follow the previous one on its context (the count from memory / in its dense form, waves
+    of the walk that refill at 16 idle lanes / only when empty, launches sized without the host learning the counts), so a
+    context's first call is not its steady state.  Results never depend on any of it; this is what it costs."""
+    ex2 = pkg.Extractor(device_index)
+    try:
+        ex2.warm_up(desc)
+        torch.cuda.synchronize()
+        wall, dev, count = [], [], []
+        ex2.debug_option("stage_timing", 1)
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            r = ex2.extract_device(buf.data_ptr(), desc, prm)
+            wall.append(round((time.perf_counter() - t0) * 1e3, 4))
+            dev.append(round(r.ms_total, 4))
+            count.append(round(r.ms_count, 4))
+        return {"wall_ms": wall, "device_ms": dev, "count_stage_ms": count,
+                "what": "call 1, 2, ... on a fresh context after cuberille_warm_up, per-stage events on"}
+    finally:
+        ex2.close()
+
+
 def cpu_baseline(pkg, torch, args, device, gpu_mesh=None, gpu_iterations=None):
     """The oracle restatement of the reference ("port"), timed on this box's host cores on a
     bounded sample of the same workload (the reference itself needs ITK).
@@ -519,6 +542,11 @@ def main():
                 out["series_two_contexts"] = series_probe(pkg, torch, ex, buf, sh.desc, prm, local_rank, max(args.steps, 10))
             except Exception as e:   # noqa: BLE001
                 out["series_two_contexts"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_slab_probe and n >= 256:
+            try:
+                out["first_calls_on_a_fresh_context"] = first_calls_probe(pkg, torch, buf, sh.desc, prm, local_rank)
+            except Exception as e:   # noqa: BLE001
+                out["first_calls_on_a_fresh_context"] = {"error": "%s: %s" % (type(e).__name__, e)}
         parity = None
         if world == 1 and args.cpu_sample > 0:
             parity, out["cpu_baseline"] = cpu_baseline(pkg, torch, args, device, mesh, int(res.proj_iterations))

@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
                                                      const u32 *__restrict__ sliceOcc, int cz0, int oz0, int oz1, long long zglob0,
                                                      int slab) {
   constexpr int ROWS = 8;
-  __shared__ u64 waveSum[16];
+  __shared__ u64 waveSum[8][16];
   __shared__ int firstOcc, topOcc, top2Occ;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the three slices of a SLAB's row (row_flags; a whole volume has no neighbours to tell): first occupied slice of the
@@ -1383,24 +1383,37 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
     tot->aliasZ = tot->topZ = tot->top2Z = -1;
   }
   u64 runV = 0, runQ = 0;
+  u64 v[ROWS], vn[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const u32 b = r * 1024 + tid;
+    vn[r] = b < nblk ? blockTot[b] : 0ull;
+  }
   for (u32 base = 0; base < nblk; base += 1024 * ROWS) {
-    u64 v[ROWS];
+    // (the next batch's totals on their way while this one is scanned)
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-      const u32 b = base + r * 1024 + tid;
-      v[r] = b < nblk ? blockTot[b] : 0ull;
+      v[r] = vn[r];
+      const u64 b = (u64)base + 1024 * ROWS + r * 1024 + tid;
+      vn[r] = b < nblk ? blockTot[b] : 0ull;
     }
+    // (the rows of a batch between ONE pair of barriers: a pair per row was 64 of them, 0.068 ms, for the 65 536 blocks of a
+    //  2048^3 volume)
+    u64 incl[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      incl[r] = wave_inclusive_sum2(v[r]);
+      if (lane == 63) waveSum[r][wv] = incl[r];
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
       if (base + r * 1024 >= nblk) break;                          // workgroup-uniform
       const u32 b = base + r * 1024 + tid;
-      const u64 incl = wave_inclusive_sum2(v[r]);
-      if (lane == 63) waveSum[wv] = incl;
-      __syncthreads();
       u64 before = 0, all = 0;
 #pragma unroll
-      for (int w = 0; w < 16; w++) { const u64 t = waveSum[w]; all += t; if (w < wv) before += t; }
-      const u64 excl = before + incl - v[r];                       // halves stay below 2^32: no carry crosses
+      for (int w = 0; w < 16; w++) { const u64 t = waveSum[r][w]; all += t; if (w < wv) before += t; }
+      const u64 excl = before + incl[r] - v[r];                    // halves stay below 2^32: no carry crosses
       const u64 bV = runV + (excl & 0xffffffffull), bQ = runQ + (excl >> 32);
       if (b < nblk) {
         blockBase[2 * (size_t)b] = bV;
@@ -1413,8 +1426,8 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
       }
       runV += all & 0xffffffffull;
       runQ += all >> 32;
-      __syncthreads();
     }
+    __syncthreads();
   }
   if (tid == 0) {
     tot->totV = runV;
