@@ -2893,7 +2893,10 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   else if (tiled >= 32) tiled -= 32;
   if (tiled && g.W <= TILE_WMAX) {
     // (slices that are whole count blocks: a workgroup walks up a column of COUNT_ZRUN blocks and re-uses two of its three planes)
-    const int want = tiled == 1 ? COUNT_ZRUN : tiled >= 4 ? tiled : 0;      // (tiled 2: one block per workgroup; >= 4: that run)
+    // (tiled 2: one block per workgroup; >= 4: that run; the pipelined dense form takes columns twice as long where those
+    //  still fill the chip: its first block is the one whose planes nobody prefetched -- 2048^3 noise 1.20 -> 1.18 ms)
+    const bool longColumns = fused && tiled == 1 && (u64)(sliceWords / COUNT_WB) * (u64)((g.oz1 - g.cz0 + 2 * COUNT_ZRUN - 1) / (2 * COUNT_ZRUN)) >= 1024;
+    const int want = tiled == 1 ? (longColumns ? 2 * COUNT_ZRUN : COUNT_ZRUN) : tiled >= 4 ? tiled : 0;
     // (... where the columns are still enough workgroups to fill the chip: a 129-slice slab of 1024^2 gives 136 columns of 8,
     //  0.107 ms against 0.05 one block per workgroup)
     const bool columnsFill = want && (u64)(sliceWords / COUNT_WB) * (u64)((g.oz1 - g.cz0 + want - 1) / want) >= 1024;

@@ -795,7 +795,7 @@ def test_2048_noise_u8_config5_full_size(pkg, extractor):
 def test_2048x2048_noise_u8_slab_of_config5_matches_oracle(pkg, oracle, extractor):
     """BASELINE.json configs[4]'s field in its full-size launch shapes against the ORACLE: a whole volume of 2048 x 2048 x
     160 uint8 voxels of the same generator (640 MiB: k_classify_span<unsigned char>; rows of 32 words, slices of 32 count
-    blocks: the LDS-tiled count in columns, which the density of the first extraction selects for the second; more than
+    blocks: the dense form of the count, which the density of the first extraction selects for the second, in every shape; more than
     2^24 vertices, 40 M triangles), iso 128, the bench's parameters -- ids, order, split and float bits, byte for byte.
     The oracle's gradient image of the full 2048^3 would be 103 GB; 160 slices are 8 GB."""
     import torch
@@ -807,7 +807,9 @@ def test_2048x2048_noise_u8_slab_of_config5_matches_oracle(pkg, oracle, extracto
     kw = dict(triangles=True, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
     prm = pkg.make_params(128, **kw)
     meshes = []
-    for variant in (0, 1):          # the count from memory / from the LDS tile in columns (the production form of this field)
+    # the count from memory / from the two-phase LDS tile / in its dense form (k_count_dense: what the history of a context
+    # picks for this field), one block per workgroup and in columns of 8 and 16 (the production shape at 2048^3)
+    for variant in (0, 1, 3, 40, 48):
         extractor.debug_option("count_variant", variant)
         res = extractor.extract_device(vol.data_ptr(), desc, prm)
         meshes.append(extractor.download())
