@@ -465,11 +465,12 @@ def test_fallback_paths_without_scratch_tables(pkg, oracle, extractor, volumes, 
         extractor.debug_option("no_such_switch", 1)
 
 
-@pytest.mark.parametrize("shape", [(128, 1024, 20), (256, 96, 24), (192, 64, 40)])
+@pytest.mark.parametrize("shape", [(128, 1024, 20), (256, 96, 24), (192, 64, 40), (64, 96, 40), (512, 24, 36)])
 def test_count_forms_agree_with_oracle(pkg, oracle, extractor, shape):
     """The three forms of the count kernel -- untiled, LDS-tiled one block per workgroup, LDS-tiled with a workgroup walking
     up a column of blocks (slices that are whole count blocks: the first shape; the others have blocks that straddle rows
-    and slices) -- on the same fields: whole volumes against the oracle, and a slab with a ghost slice against the whole."""
+    and slices; rows of ONE word, where every word is a row's first and last; rows of eight words in slices of 192) -- on the
+    same fields: whole volumes against the oracle, and a slab with a ghost slice against the whole."""
     import torch
     nx, ny, nz = shape
     vox = pkg.volumes.gradient_noise(nx, ny, nz, base_period=32)
