@@ -1182,7 +1182,8 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
         prm = pkg.make_params(iso, **kw)
         ex = pkg.Extractor(0)
         for o in options:
-            ex.debug_option(o, 1)
+            name, _, value = o.partition("=")
+            ex.debug_option(name, int(value or 1))
         sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.from_numpy(vox[:1]).dtype, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vox[sh.z0:sh.z1]).cuda()      # owned slices only
@@ -1212,7 +1213,8 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
 
 @pytest.mark.parametrize("case", ["two_voxels_empty_rank_between", "source_in_the_halo", "source_in_the_halo_no_corner_map",
                                   "marschner_lobb_stacked", "ghost_lowest_occupied", "ghost_source_in_the_halo",
-                                  "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source", "nothing_occupied_below"])
+                                  "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source", "nothing_occupied_below",
+                                  "source_in_the_halo_dense_count", "ghost_source_below_the_buffer_dense_count"])
 def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case):
     """Quirk Q1 (txx:139-141 before 156-161) when the run of empty slices contains a slab boundary: the rank above
     re-uses vertices the rank below created.  Real processes over gloo on this box's GPU: the source slice's inside
@@ -1237,16 +1239,20 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         vox[40:50] = (rng.random((10, 12, 70)) < 0.3) * 255
         iso, world = 128, 2
     elif case.startswith("source_in_the_halo"):
+        # (..._dense_count: rows of whole words, so that the dense form of the count -- k_count_dense, forced -- meets the
+        #  aliased source slice, in the buffer here, handed over by the rank below in the ghost case further down)
+        nx_ = 128 if case.endswith("dense_count") else 70
         rng = np.random.default_rng(3)
-        vox = np.zeros((40, 12, 70), dtype=np.uint8)        # cut at 20; slices 16..21 empty, source slice 15 in the halo
-        vox[8:16] = (rng.random((8, 12, 70)) < 0.3) * 255
-        vox[22:30] = (rng.random((8, 12, 70)) < 0.3) * 255
+        vox = np.zeros((40, 12, nx_), dtype=np.uint8)       # cut at 20; slices 16..21 empty, source slice 15 in the halo
+        vox[8:16] = (rng.random((8, 12, nx_)) < 0.3) * 255
+        vox[22:30] = (rng.random((8, 12, nx_)) < 0.3) * 255
         iso, world = 128, 2
     elif case.startswith("ghost"):
         # the aliased slice is a rank's GHOST slice (the last slice of the rank below): round-2 advisor finding, the
         # plan then took the ghost slice itself for the source and the cells of the first owned slice came out wrong
         rng = np.random.default_rng(11)
-        fill = lambda a, b: (rng.random((b - a, 12, 70)) < 0.3) * 255
+        nx_ = 64 if case.endswith("dense_count") else 70
+        fill = lambda a, b: (rng.random((b - a, 12, nx_)) < 0.3) * 255
         if case == "ghost_lowest_occupied":                 # cut at 20; slice 19 is the lowest occupied slice of the volume
             vox = np.zeros((40, 12, 70), dtype=np.uint8)
             vox[19:28] = fill(19, 28)
@@ -1256,8 +1262,8 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
             vox[14:16] = fill(14, 16)
             vox[19:28] = fill(19, 28)
             iso, world = 128, 2
-        elif case == "ghost_source_below_the_buffer":       # cut at 32, buffer from 24; 10..12, then 31.. occupied
-            vox = np.zeros((64, 12, 70), dtype=np.uint8)
+        elif case.startswith("ghost_source_below_the_buffer"):       # cut at 32, buffer from 24; 10..12, then 31.. occupied
+            vox = np.zeros((64, 12, nx_), dtype=np.uint8)
             vox[10:13] = fill(10, 13)
             vox[31:40] = fill(31, 40)
             iso, world = 128, 2
@@ -1278,7 +1284,7 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ()
+    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ("count_variant=34",) if case.endswith("dense_count") else ()
     mp.spawn(_q1_worker, args=(world, port, str(tmp_path / "vol.npy"), iso, kw, str(tmp_path), options), nprocs=world, join=True)
 
     class M:
@@ -1298,7 +1304,8 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         # the aliased slice is the lowest occupied slice of the volume: no source, nothing to hand over -- decided from the
         # rows on the device since the second-highest occupied slices ride in them
         assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank[1:]), stats
-    elif case in ("two_voxels_empty_rank_between", "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source"):
+    elif case in ("two_voxels_empty_rank_between", "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source",
+                  "ghost_source_below_the_buffer_dense_count"):
         # a real hand-over: the synchronous protocol with its gathers, every step
         assert all(st["collectives"] >= 2 for per_rank in stats for st in per_rank), stats
 
