@@ -132,7 +132,7 @@ struct Tuning {
   int count_variant = -1;     // 1: the count kernel reads its bit rows from an LDS tile (in columns of 8 blocks where slices are
                               // whole blocks), 2: the tile, one block per workgroup, 4 .. 31: columns of that many, 0: from memory,
                               // 3 / 32 + one of those: the dense form (k_count_dense: one phase, corner logic per lattice corner,
-                              // pipelined columns) where rows are a power of two of whole words, else the tile as 1 / that,
+                              // pipelined columns) where rows are a power of two of words, else the tile as 1 / that,
                               // -1: the dense form when the previous extraction on the context found vertices in a quarter of its
                               //     words, else from memory
   // the walk: vertices per batch (0: 64 when the launch leaves wave slots empty, else 128), waves in the grid, idle lanes

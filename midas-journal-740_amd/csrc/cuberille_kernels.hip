@@ -858,8 +858,16 @@ __device__ __forceinline__ void lattice_word(const DenseAt &w, const u64 *__rest
     P[0] &= ~L0; R[0] &= ~L0; P[1] &= ~L1; R[1] &= ~L1;
   }
   nibs = ((u32)R[0] & 1u) + ((u32)R[1] & 1u) + ((u32)R[2] & 1u) + ((u32)R[3] & 1u);
-  const u64 nw = w.tile[w.idx + (w.k < w.W - 1 ? 1 : 0)];
-  const u64 p11 = (I >> 1) | (w.k < w.W - 1 ? (nw << 63) : (I & (1ull << 63)));
+  const bool last = w.k == w.W - 1;
+  if (last && g.lastpos != 63) {
+    // a row that ends inside its last word: the corners X = nx are bit lastpos + 1 of this word's R -- evaluated with the
+    // zero bits of the voxels that do not exist, and the x-border pass's to supply, like those behind a whole last word
+    const u64 keep = ~(2ull << g.lastpos);
+#pragma unroll
+    for (int r = 0; r < 4; r++) R[r] &= keep;
+  }
+  const u64 nw = w.tile[w.idx + (last ? 0 : 1)];
+  const u64 p11 = (I >> 1) | (last ? (I & (1ull << g.lastpos)) : (nw << 63));      // (the clamped neighbour of the row's last voxel: itself)
   // (at X = 0 the face test reads the clamped neighbour: voxel 0 itself)
   const u64 m11 = first ? (m[1][1] | 1ull) : m[1][1];
   const int nQ = popc64(I & ~m11) + popc64(I & ~c[1][0]) + popc64(I & ~p11) + popc64(I & ~c[1][2]) + popc64(I & ~c[0][1]) + popc64(I & ~c[2][1]);
@@ -877,7 +885,8 @@ __device__ __forceinline__ void lattice_word(const DenseAt &w, const u64 *__rest
 // lo: the first word of the row in the staged rows (AT_START) or its last one; returns how many of the four are set.
 template <bool AT_START>
 __device__ __forceinline__ u32 border_nibs(const DenseAt &w, const u64 *__restrict__ bits, const Grid &g, int zp) {
-  const u32 *t32 = reinterpret_cast<const u32 *>(w.tile) + (AT_START ? 0 : 1);     // bit 0 of the low dword / bit 31 of the high one
+  // bit 0 of the first word's low dword / the bit of the row's last voxel in its last word
+  const u32 *t32 = reinterpret_cast<const u32 *>(w.tile) + (AT_START ? 0 : g.lastpos >> 5);
   u32 exy[3] = {~0u, ~0u, ~0u}, exz[3] = {~0u, ~0u, ~0u};
   int yo[3] = {-w.W, 0, w.W}, zo[3] = {w.below, 0, w.above};
   if (w.y == 0) { exy[0] = 0u; yo[0] = 0; }
@@ -914,12 +923,12 @@ __device__ __forceinline__ u32 border_nibs(const DenseAt &w, const u64 *__restri
   }
   if (zp >= 0) {
     // quirk Q1 (see lattice_word): the aliased source slice's voxels at x = 0 / x = nx-1 of rows y-1, y, y+1
-    const u32 *s32 = reinterpret_cast<const u32 *>(bits + ((size_t)zp * g.ny + w.y) * g.W + w.k) + (AT_START ? 0 : 1);
+    const u32 *s32 = reinterpret_cast<const u32 *>(bits + ((size_t)zp * g.ny + w.y) * g.W + w.k) + (AT_START ? 0 : g.lastpos >> 5);
     const u32 a0 = s32[2 * yo[0]] & exy[0], a1 = s32[0], a2 = s32[2 * yo[2]] & exy[2];
     created[0] &= ~(a0 | a1);
     created[1] &= ~(a1 | a2);
   }
-  const u32 any4 = AT_START ? 0u : 31u;
+  const u32 any4 = AT_START ? 0u : (u32)(g.lastpos & 31);
   return ((created[0] >> any4) & 1u) + ((created[1] >> any4) & 1u) + ((created[2] >> any4) & 1u) + ((created[3] >> any4) & 1u);
 }
 
@@ -1132,7 +1141,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2, the DENSE form (a surface that touches most words; rows of whole words, a power of two of them, so that a row never
+// K2, the DENSE form (a surface that touches most words; rows of a power of two of words -- whole or not -- so that a row never
 // straddles two blocks).  Same outputs as k_count, another shape:
 //   * ONE phase instead of two: every word of the block, in raster order, takes its faces and its corner logic from the
 //     same nine staged rows, the corner logic per lattice corner (lattice_word: the closed forms, no x+1 rows, no queue of
@@ -1257,7 +1266,7 @@ __global__ __launch_bounds__(512, 4) void k_count_dense(const u64 *__restrict__ 
           if (tile[da.idx] & 1ull) nibs = border_nibs<true>(da, bits, g, zp);
         } else {
           da.idx += g.W - 1; da.k = g.W - 1;
-          if (tile[da.idx] >> 63) nibs = border_nibs<false>(da, bits, g, zp);
+          if ((tile[da.idx] >> g.lastpos) & 1ull) nibs = border_nibs<false>(da, bits, g, zp);
         }
       }
       if (atStart) seamF[v] = (unsigned char)nibs;
@@ -2887,8 +2896,8 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
   const size_t sliceWords = (size_t)g.ny * g.W;
   // (tiled 3, or 32 + one of the values below: the dense form -- faces and corner logic in one phase, per lattice corner --
-  //  where rows are whole words and a power of two of them, else the two-phase tile)
-  const bool fused = (tiled == 3 || tiled >= 32) && g.wShift >= 0 && g.lastpos == 63;
+  //  where a row is a power of two of words, else the two-phase tile)
+  const bool fused = (tiled == 3 || tiled >= 32) && g.wShift >= 0;
   if (tiled == 3) tiled = 1;
   else if (tiled >= 32) tiled -= 32;
   if (tiled && g.W <= TILE_WMAX) {
