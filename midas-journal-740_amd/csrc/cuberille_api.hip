@@ -46,6 +46,24 @@ struct DevBuf {
     return hipSuccess;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  // When the buffer has to grow anyway, grow it to `cover` -- what the NEXT extraction on the context will ask for when it is
+  // launched from this one's sizes (cuberille_step_begin: + 25 %) -- so that the second extraction of a series does not
+  // free and allocate the mesh buffers again (176 ms of one 14 ms extraction at 2048^3); back to `bytes` if that is too much.
+  hipError_t reserve_covering(size_t bytes, size_t cover) {
+    if (bytes <= cap) return hipSuccess;
+    if (cover > bytes) {
+      if (g_fail_alloc_countdown < 0) {          // (the failure drill counts one allocation per buffer: keep it so)
+        const size_t had = cap;
+        cap = 0;
+        if (p) { (void)hipFree(p); p = nullptr; }
+        if (hipMalloc(&p, cover + 256) == hipSuccess) { cap = cover + 256; return hipSuccess; }
+        (void)hipGetLastError();
+        p = nullptr;
+        (void)had;
+      }
+    }
+    return reserve(bytes);
+  }
 };
 
 // Host memory of the context's own (cuberille_mesh_host): anonymous pages, 2 MiB aligned and advised as huge pages where
@@ -709,8 +727,12 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   const u32 nVW = dyn ? coverVW : c->tot.nVertexWords;
   // room behind this rank's points for the positions of a plane of the rank below's vertices (quirk Q1 across slabs)
   const size_t planeCorners = (c->slabMode || c->g.extAlias) ? (size_t)(c->g.nx + 1) * (c->g.ny + 1) : 0;
-  HIP_TRY(c, c->points.reserve((size_t)(nV + planeCorners ? nV + planeCorners : 1) * 3 * sizeof(float)));
-  HIP_TRY(c, c->cells.reserve((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
+  // (a first extraction also makes room for the blind launches of the one behind it: gate.coverV / coverQ of cuberille_step_begin)
+  const u64 nextV = dyn ? nV : nV + nV / 4 + 4096, nextQ = dyn ? nQ : totQ + totQ / 4 + 4096;
+  HIP_TRY(c, c->points.reserve_covering((size_t)(nV + planeCorners ? nV + planeCorners : 1) * 3 * sizeof(float),
+                                        (size_t)(nextV + planeCorners) * 3 * sizeof(float)));
+  HIP_TRY(c, c->cells.reserve_covering((size_t)(nQ ? nQ : 1) * (c->prm.triangles ? 6 : 4) * sizeof(u64),
+                                       (size_t)nextQ * (c->prm.triangles ? 6 : 4) * sizeof(u64)));
   Workspace &w = c->w;
   w.points = (float *)c->points.p;
   w.cells = (u64 *)c->cells.p;
@@ -727,8 +749,10 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
   // head tables for the per-wave inverse mapping (4 B per 64 outputs)
   w.headV = w.headQ = nullptr;
   if (c->nwords < 0xffffffffULL && !c->tune.no_heads) {
-    if (c->headQ.reserve((size_t)(totQ / 64 + 2) * sizeof(u32)) == hipSuccess) w.headQ = (u32 *)c->headQ.p;
-    if (!w.vqueue && c->headV.reserve((size_t)(nV / 64 + 2) * sizeof(u32)) == hipSuccess) w.headV = (u32 *)c->headV.p;
+    if (c->headQ.reserve_covering((size_t)(totQ / 64 + 2) * sizeof(u32), (size_t)(nextQ / 64 + 2) * sizeof(u32)) == hipSuccess)
+      w.headQ = (u32 *)c->headQ.p;
+    if (!w.vqueue && c->headV.reserve_covering((size_t)(nV / 64 + 2) * sizeof(u32), (size_t)(nextV / 64 + 2) * sizeof(u32)) == hipSuccess)
+      w.headV = (u32 *)c->headV.p;
     (void)hipGetLastError();
   }
   // THIN_HALO: room for the vertices whose walk leaves the buffer (more than these: the step is redone with the deep halo)
