@@ -491,7 +491,7 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
   HIP_TRY(c, c->occ.reserve(sizeof(Totals) + (size_t)g.nzb * sizeof(u32)));
   HIP_TRY(c, c->prefix.reserve((nwords + 4) * sizeof(u32)));   // (+ the tail of a 16-byte read at the last words: locate_word_wave)
   HIP_TRY(c, c->segPre.reserve(nseg * sizeof(u64)));
-  HIP_TRY(c, c->blockTot.reserve(nblk * sizeof(u64)));
+  HIP_TRY(c, c->blockTot.reserve((nblk + 2 * (nblk / 8192 + 1)) * sizeof(u64)));     // (+ the sums of its chunks of 8192: k_block_partial)
   HIP_TRY(c, c->blockBase.reserve(nblk * 2 * sizeof(u64)));
   Workspace w{};
   w.flatBits = nullptr;
@@ -1401,7 +1401,7 @@ int cuberille_warm_up(cuberille_ctx *c, const cuberille_image_desc *img, const c
   ok = ok && c->occ.reserve(sizeof(Totals) + nz * sizeof(u32)) == hipSuccess;
   ok = ok && c->prefix.reserve((nwords + 4) * sizeof(u32)) == hipSuccess;
   ok = ok && c->segPre.reserve(nseg * sizeof(u64)) == hipSuccess;
-  ok = ok && c->blockTot.reserve(nblk * sizeof(u64)) == hipSuccess;
+  ok = ok && c->blockTot.reserve((nblk + 2 * (nblk / 8192 + 1)) * sizeof(u64)) == hipSuccess;
   ok = ok && c->blockBase.reserve(nblk * 2 * sizeof(u64)) == hipSuccess;
   if (ok && nx % 64 != 0) ok = c->flatBits.reserve((nwords + 32) * sizeof(u64)) == hipSuccess;
   if (ok && nwords < 0xffffffffULL && !c->tune.no_vqueue) ok = c->vqueue.reserve(nwords * sizeof(u32)) == hipSuccess;

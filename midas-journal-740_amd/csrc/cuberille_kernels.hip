@@ -1344,6 +1344,34 @@ __global__ __launch_bounds__(512, 4) void k_count_dense(const u64 *__restrict__ 
   }
 }
 
+// More than 8192 count blocks (volumes beyond 1024^3): the scan below runs as one workgroup per chunk of 8192 blocks, each
+// starting from the sums of the chunks before it -- which this launch leaves behind the block totals, blockTot[nblk + 2j]
+// (vertices) and [nblk + 2j + 1] (quads) for chunk j.  (One workgroup walking 65 536 totals in eight dependent batches was
+// 0.056 ms of a 2048^3 volume's pass.)
+constexpr u32 SCAN_CHUNK = 8192;
+__global__ __launch_bounds__(1024) void k_block_partial(u64 *__restrict__ blockTot, u32 nblk) {
+  __shared__ u64 sumV[16], sumQ[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const u32 first = blockIdx.x * SCAN_CHUNK;
+  u64 v = 0, q = 0;
+#pragma unroll
+  for (int r = 0; r < (int)(SCAN_CHUNK / 1024); r++) {
+    const u32 b = first + r * 1024 + tid;
+    const u64 t = b < nblk ? blockTot[b] : 0ull;
+    v += t & 0xffffffffull;
+    q += t >> 32;
+  }
+  for (int sft = 32; sft > 0; sft >>= 1) { v += __shfl_xor(v, sft, 64); q += __shfl_xor(q, sft, 64); }
+  if (lane == 0) { sumV[wv] = v; sumQ[wv] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    u64 a = 0, c = 0;
+    for (int w = 0; w < 16; w++) { a += sumV[w]; c += sumQ[w]; }
+    blockTot[(size_t)nblk + 2 * blockIdx.x] = a;
+    blockTot[(size_t)nblk + 2 * blockIdx.x + 1] = c;
+  }
+}
+
 // Exclusive scan of the count blocks' totals (V | Q<<32 each) -> blockBase[2b], [2b+1] and the grand totals.  One
 // workgroup: rows of 1024 consecutive blocks, coalesced loads, ROWS rows in flight at once (the loads are what
 // takes time), then per row a workgroup-wide exclusive scan; V and Q of a row fit 32 bits each (1024 x 2^21),
@@ -1360,6 +1388,11 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the three slices of a SLAB's row (row_flags; a whole volume has no neighbours to tell): first occupied slice of the
   // counted range, highest and second-highest occupied owned slice.  Wave reductions, then one LDS atomic per wave.
+  // (gridDim.x > 1: this workgroup scans chunk blockIdx.x of SCAN_CHUNK blocks, from the sums k_block_partial left)
+  const u32 chunk = blockIdx.x, nchunks = gridDim.x;
+  if (chunk > 0) {
+    // (the slab's three slices, the totals and the gate belong to the first / last workgroup)
+  } else
   if (slab) {
     auto wave_min = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o < v ? o : v; } return v; };
     auto wave_max = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o > v ? o : v; } return v; };
@@ -1392,13 +1425,20 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
     tot->aliasZ = tot->topZ = tot->top2Z = -1;
   }
   u64 runV = 0, runQ = 0;
+  const u32 nblkAll = nblk;
+  u32 base0 = 0;
+  if (nchunks > 1) {
+    for (u32 j = 0; j < chunk; j++) { runV += blockTot[(size_t)nblkAll + 2 * j]; runQ += blockTot[(size_t)nblkAll + 2 * j + 1]; }
+    base0 = chunk * SCAN_CHUNK;
+    nblk = base0 + SCAN_CHUNK < nblkAll ? base0 + SCAN_CHUNK : nblkAll;      // (this workgroup's blocks: [base0, nblk))
+  }
   u64 v[ROWS], vn[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
-    const u32 b = r * 1024 + tid;
+    const u32 b = base0 + r * 1024 + tid;
     vn[r] = b < nblk ? blockTot[b] : 0ull;
   }
-  for (u32 base = 0; base < nblk; base += 1024 * ROWS) {
+  for (u32 base = base0; base < nblk; base += 1024 * ROWS) {
     // (the next batch's totals on their way while this one is scanned)
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
@@ -1438,7 +1478,7 @@ __global__ __launch_bounds__(1024) void k_block_scan(const u64 *__restrict__ blo
     }
     __syncthreads();
   }
-  if (tid == 0) {
+  if (tid == 0 && chunk == nchunks - 1) {
     tot->totV = runV;
     tot->totQ = runQ;
     if (gate.on) {
@@ -2926,7 +2966,9 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals, 0);
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
-  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0,
+  const unsigned chunks = blocks > SCAN_CHUNK ? (blocks + SCAN_CHUNK - 1) / SCAN_CHUNK : 1;
+  if (chunks > 1) hipLaunchKernelGGL(k_block_partial, dim3(chunks), dim3(1024), 0, s, w.blockTot, blocks);
+  hipLaunchKernelGGL(k_block_scan, dim3(chunks), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0,
                      g.gnz != (long long)g.nzb ? 1 : 0);
   return hipGetLastError();
 }
