@@ -4,6 +4,8 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: bench.py starts that same command itself, as a child process, before it
+                                       touches the GPU; an attempt that ends without a line is followed by the plain protocol)
 
 A "step" is one complete extraction (the whole GenerateData() path: classify, count,
 scan, emit, projection, triangle split) of a volume already resident in HBM.
@@ -234,6 +236,101 @@ def cpu_baseline(pkg, torch, args, device, gpu_mesh=None, gpu_iterations=None):
     }
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv, port):
+    """The command `bench.py --gpus N` starts when nobody wrapped it in torch.distributed.run: the contract's own launch
+    line, one rank per GPU, the same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+# the ladder a self-launched N>1 run goes down when an attempt ends without a JSON line (non-zero exit, or no end within
+# --launch-timeout): the default step first, then the protocol with the host in the loop and the full halo, equal slabs
+# (nothing blind, nothing on a side stream, no second communicator).  A slower curve is worth more than none.
+LAUNCH_LADDER = [
+    ([], None),
+    (["--host-offsets", "--full-halo", "--partition", "uniform"],
+     "the default N>1 step did not finish (%s): plain protocol -- host-side offsets, full halo, slabs of equal thickness"),
+]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell (WORLD_SIZE unset, N > 1): start the ranks as a CHILD process -- this
+    process never touches HIP, so nothing that has initialised the GPU is ever replaced -- pass their output through,
+    return their exit code.  The JSON line is the child's rank 0's."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc, why = 1, ""
+    for extra, note in LAUNCH_LADDER:
+        cmd = launcher_command(args.gpus, argv + extra + (["--fallback-note", note % why] if note else []), free_port())
+        print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
+        try:
+            out, _ = proc.communicate(timeout=args.launch_timeout)
+            rc = proc.returncode
+            why = "exit code %d" % rc
+        except subprocess.TimeoutExpired:
+            # the whole process group of the launcher: its ranks must not outlive it on the GPUs
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                try:
+                    proc.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = proc.communicate()
+            rc, why = 124, "no end within %d s" % args.launch_timeout
+        lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+        sys.stdout.write(out or "")
+        sys.stdout.flush()
+        if rc == 0 and lines:
+            return 0
+        if lines:            # a line was printed and the run failed afterwards (e.g. a parity check): that is the result
+            return rc
+        print("bench.py: %d ranks ended without a result (%s)" % (args.gpus, why), file=sys.stderr, flush=True)
+        if args.no_launch_fallback:
+            break
+    return rc or 1
+
+
+class Watchdog:
+    """A wall-clock guard around a stretch that can only hang, never raise (the first collectives of an N>1 run): if it
+    is not left within `seconds`, say where, and end the process with exit code 3 -- torch.distributed.run then ends the
+    other ranks -- instead of sitting in a collective until somebody's patience runs out."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.what, self.seconds = what, seconds
+        self._done = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        if not self._done.wait(self.seconds):
+            sys.stderr.write("bench.py: rank %s: %s did not finish within %d s -- giving up (exit 3)\n" % (
+                os.environ.get("RANK", "0"), self.what, self.seconds))
+            sys.stderr.flush()
+            os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,7 +368,20 @@ def main():
                          "of the per-kernel averages this way; the untimed warm-up steps do the warming then)")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="N=1: skip the extra measurement of one 1/8 slab (what a rank of an 8-GPU run does per step)")
+    ap.add_argument("--launch-timeout", type=int, default=600,
+                    help="--gpus N > 1 from a bare shell: seconds one attempt of the self-started ranks may take")
+    ap.add_argument("--no-launch-fallback", action="store_true",
+                    help="--gpus N > 1 from a bare shell: do not try the plain protocol when the default step ends without a line")
+    ap.add_argument("--step-timeout", type=int, default=240,
+                    help="N>1: seconds the start of the process group, the first step, or the timed region may take before "
+                         "the rank gives up with exit code 3 (0 = wait forever)")
+    ap.add_argument("--fallback-note", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: the ranks are started HERE, as a child process, before this process has
+        # imported torch or touched HIP (a process that has initialised the GPU is never replaced by another program)
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -280,8 +390,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
-            args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
+                         "(or with no launcher at all: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
+
+    def guard(what, scale=1):
+        return Watchdog(args.step_timeout * scale if world > 1 else 0, what)
     # CUBERILLE_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a functional rehearsal of
     # the N>1 path on a one-GPU box (never a measurement)
     rehearsal = os.environ.get("CUBERILLE_BENCH_REHEARSAL") == "1"
@@ -290,10 +403,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        with guard("the start of the process group"):
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=device)
     pkg = graft.load_package()
     # the library is built by __graft_entry__.build(); here only make sure it exists, and never let
     # several ranks run the compiler on the same output at once
@@ -340,7 +454,9 @@ def main():
         torch.cuda.synchronize()
 
     res = None
-    fallback = None
+    fallback = args.fallback_note
+    first_step = guard("the first step of the N>1 path (the first halo exchange and row all-gather between the ranks)")
+    first_step.__enter__()
     if world > 1 and not args.host_offsets:
         # the first step of the N>1 path on this node: should the one-wait step (device-resident rows, thin halo) raise on
         # ANY rank, every rank learns of it here and all take the plain protocol (host in the loop, full halo) instead -- a
@@ -360,7 +476,10 @@ def main():
             res = None
     for _ in range(args.warmup):
         res = sh.extract(buf, prm)
+    first_step.__exit__(None, None, None)
     partition = "uniform"
+    rest = guard("the calibration, the timed region or what follows it", scale=4)
+    rest.__enter__()
     if world > 1 and strong and args.partition == "balanced":
         # the surface of a volume is rarely spread evenly over z (this field's rippled sheet lies in a sixth of the
         # slices): one calibration step on slabs of equal thickness measures what every slice costs, the slabs of the
@@ -558,6 +677,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    rest.__exit__(None, None, None)
 
 
 if __name__ == "__main__":
