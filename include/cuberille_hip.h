@@ -192,7 +192,10 @@ void cuberille_destroy(cuberille_ctx *ctx);
  * the image description alone: the device copy of the volume (cuberille_extract_host), the bit volume, the prefix
  * tables, the vertex-word queue, the corner map, the pinned staging ring of a chunked upload.  `prm` may be null (the
  * defaults of txx:33-40).  The drop-in filter calls it from its constructor (no image) and from SetInput (the image's
- * description).  A failed reservation is not an error: the extraction will ask again and report it. */
+ * description).  A failed reservation is not an error: the extraction will ask again and report it.  On a context that
+ * holds a count, a mesh or an open step the call reserves nothing and runs nothing (growing a buffer moves it, and the
+ * count's tables, the bit volume and the mesh stay readable until the next extraction replaces them): that extraction
+ * grows the workspace itself. */
 int cuberille_warm_up(cuberille_ctx *ctx, const cuberille_image_desc *img, const cuberille_params *prm);
 /* run on a caller's hipStream_t instead of the context's own (NULL = back to own) */
 int cuberille_set_stream(cuberille_ctx *ctx, void *hip_stream);

@@ -1351,6 +1351,12 @@ int cuberille_warm_up(cuberille_ctx *c, const cuberille_image_desc *img, const c
   dflt.iso_value = 1.0; dflt.generate_triangles = 1; dflt.project_vertices = 1; dflt.distance_threshold = 0.5;
   dflt.step_length = -1.0; dflt.relaxation = 0.95; dflt.max_steps = 50; dflt.emulate_empty_slice_aliasing = 1;
   dflt.iso_value_int = 1;
+  // A count, a mesh or an open step on the context: its workspace is in use -- the toy extraction would replace the state,
+  // and DevBuf::reserve frees before it allocates, which would leave the workspace pointers of the live count (c->w, the
+  // bit volume) dangling under cuberille_emit / _recount / _slice_bits_device / _alias_plane_device / _debug_bits.
+  // Such a context has run kernels already; the next extraction grows what it needs itself.
+  const bool live = c->counted || c->haveMesh || c->stepMode != 0;
+  if (live) c->warm = true;
   if (!c->warm) {
     // one tiny extraction: the first launch of any kernel loads the library's code objects, the first copies and events
     // set up the runtime's queues.  8 x 8 x 8 voxels with a 4 x 4 x 4 block inside; nothing of it stays on the context.
@@ -1391,6 +1397,7 @@ int cuberille_warm_up(cuberille_ctx *c, const cuberille_image_desc *img, const c
   for (int i = 0; i < 3; i++)
     if (img->dims[i] < 1 || img->dims[i] > 0x7fffffffLL) return fail(c, CUBERILLE_ERR_ARGUMENT, "image dimensions out of range");
   (void)prm;
+  if (live) return CUBERILLE_OK;
   // the buffers whose size follows from the description (count_prepare, emit_points_phase, cuberille_extract_host); a
   // reservation that fails here is asked for again, and reported, by the extraction
   const size_t nx = (size_t)img->dims[0], ny = (size_t)img->dims[1], nz = (size_t)img->dims[2];

@@ -648,7 +648,26 @@ class ShardedExtractor:
         if plan and not self.cross_slab_aliasing:
             raise RuntimeError("empty-slice aliasing (reference quirk Q1) crosses the slab boundary below rank %d" % plan[0][0])
         if thin:
-            escaped = rows[:, ROW_ESCAPED]
+            escaped = rows[:, ROW_ESCAPED].copy()
+            late = rows[:, ROW_ALIAS_Z] >= 0
+            if not plan and late.any():
+                # (round-4 advisor finding) A rank whose first occupied slice has only empty slices below it in its buffer
+                # could not say before the gather whether its counts stand -- so its vertex phase, and with it the number
+                # of its walks that left the thin halo, did not travel with the counts (on a resumed step the walks HAVE
+                # run, blindly, and may have escaped).  No rank below holds a source: the counts stand.  Those ranks run
+                # (or look at) their vertex phase now and every rank learns of their escapes in a second, small gather --
+                # every rank sees `late` in the rows, so all of them take this turn together.
+                if late[self.rank] and failed is None:
+                    try:
+                        self.ex.emit_points()
+                        n_esc = self.ex.escaped_count()
+                        self.stats["host_syncs"] += 1
+                    except _abi.CuberilleError as e:
+                        failed = e
+                rows_e = gather_counts(0, 0, dev, self.group, extra=(n_esc, 0 if failed is None else 1))
+                self.stats["collectives"] += 1
+                self._raise_if_any_failed(rows_e[:, 3], "cuberille_emit_points", failed)
+                escaped = np.where(late, rows_e[:, 2], escaped)
             self.stats["escaped"] = int(n_esc)
             overflow = (escaped >= _abi.ESCAPED_OVERFLOW).any()
             if plan or overflow or escaped.any():
@@ -729,12 +748,13 @@ class ShardedExtractor:
                 ids.fill_(-2)
             _p2p_send(ids, r, self.group)
             _p2p_send(pts, r, self.group)
-        if plan:
-            # the hand-over made ranks depend on each other after the counts were agreed: close the step together
-            ok = gather_counts(0, 0, dev, self.group, extra=(0 if failed is None else 1,))
-            self._raise_if_any_failed(ok[:, 2], "cuberille_emit", failed)
-        elif failed is not None:
-            raise failed
+        # close the step together: a hand-over made ranks depend on each other after the counts were agreed -- and without
+        # one, a rank whose emit fails alone (out of memory for its part of the mesh, say) must not leave the others on
+        # their way into the next step's collectives (round-4 advisor finding).  This is the protocol with the host in
+        # the loop: one more small gather does not change what it costs.
+        ok = gather_counts(0, 0, dev, self.group, extra=(0 if failed is None else 1,))
+        self.stats["collectives"] += 1
+        self._raise_if_any_failed(ok[:, 2], "cuberille_emit", failed)
         return res
 
     def slice_work(self, result):

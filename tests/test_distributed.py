@@ -223,7 +223,13 @@ def _fake_worker(rank, world, port, scenario, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         nz, ny, nx = 40, 4, 6
-        calls = {}
+        calls = {"gathers": 0}
+        real_gather = D.gather_counts
+
+        def counting_gather(*a, **kw):
+            calls["gathers"] += 1
+            return real_gather(*a, **kw)
+        D.gather_counts = counting_gather
 
         def count(ptr, desc, params, slab):
             calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
@@ -237,17 +243,22 @@ def _fake_worker(rank, world, port, scenario, out_dir):
             SI = pkg.cuberille.SlabInfo
             if scenario in ("alias", "recount_fails"):
                 return SI(rank == 1, 0, 5 if rank == 0 else 30, 4 if rank == 0 else 29, 25 if rank == 1 else -1)
-            if scenario == "alias_nothing_below":
+            if "alias_nothing_below" in scenario:
                 return SI(rank == 1, -1, -1 if rank == 0 else 30, -1 if rank == 0 else 29, 25 if rank == 1 else -1)
             return SI(False, 0, nz - 1, nz - 2, -1)
 
         def emit(poff):
+            if scenario == "emit_fails" and rank == 1:
+                raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic emit failure")
+            if scenario.endswith("escape") and rank == 1 and "reprojected" not in calls:
+                # what the library says while walks wait for slices the thin buffer lacks
+                raise pkg._abi.CuberilleError(pkg._abi.ERR_HALO, "5 walks left the thin halo")
             calls["offsets"] = (poff,)
             return types.SimpleNamespace(n_points=100 + rank, n_cells=7 * (rank + 1), verts_per_cell=3)
         def emit_points():
-            # only a rank whose counts nothing can change may start early
-            calls["early"] = True
-            assert slab_info().alias_z < 0
+            # only a rank whose counts nothing can change may start early: before the counts are gathered
+            calls["points_emitted"] = True
+            assert slab_info().alias_z < 0 or calls["gathers"] >= 1
 
         def slice_bits_device(zp):
             calls["served_bits"] = zp
@@ -258,7 +269,9 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         def recount(ptr):
             raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic recount failure")
         def escaped_count():
-            return 5 if (scenario == "thin_escape" and rank == 1) else 0
+            if not calls.get("points_emitted"):
+                raise pkg._abi.CuberilleError(pkg._abi.ERR_STATE, "cuberille_escaped_count follows cuberille_emit_points")
+            return 5 if (scenario.endswith("escape") and rank == 1) else 0
 
         def reproject_escaped(ptr, z_begin, nz_):
             calls["reprojected"] = (z_begin, nz_)
@@ -273,10 +286,16 @@ def _fake_worker(rank, world, port, scenario, out_dir):
 
             def step_begin(ptr, desc, params, slab):
                 calls["slab"] = (slab.global_nz, slab.z_begin, slab.own_z0, slab.own_z1)
+                calls["thin"] = int(slab.flags)
                 if scenario == "step_begin_fails" and rank == 1:
                     raise pkg._abi.CuberilleError(pkg._abi.ERR_HIP, "synthetic step_begin failure")
                 row = np.zeros(NW, dtype=np.int64)
                 row[0], row[1] = 100 + rank, 7 * (rank + 1)
+                if scenario.endswith("escape") and rank == 1:
+                    # the blind vertex phase ran and a walk left the thin halo: the flag rides in the row (the low half of
+                    # word 6 holds the flags), the step comes back with CUBERILLE_RETRY on every rank
+                    row[6] = 8
+                    calls["points_emitted"] = True
                 calls["row"] = row
                 return row.ctypes.data, row.nbytes
 
@@ -295,11 +314,11 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         # (handing the source slice over needs the GPU library: tests/test_gpu_parity.py; here the case is refused, or,
         #  "recount_fails", taken up to the consumer's recount, which fails: every rank must raise, none may hang)
         sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm,
-                                cross_slab_aliasing=scenario == "recount_fails", thin_halo=scenario.startswith("thin"),
+                                cross_slab_aliasing=scenario == "recount_fails", thin_halo="thin" in scenario,
                                 close_steps=scenario == "step_end_fails")
         sh.force_step_path = scenario.startswith("step")
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
-        assert sh.thin == ((3, 3) if scenario.startswith("thin") else None)
+        assert sh.thin == ((3, 3) if "thin" in scenario else None)
         # every slice of the buffer says which slice it is: the exchanges must bring exactly the halo they are asked for
         buf = torch.full((sh.hi - sh.lo, ny, nx), -1.0)
         for z in range(sh.z0, sh.z1):
@@ -317,9 +336,9 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         except ValueError as e:
             too_far = str(e)
         assert "halo" in too_far
-        if scenario.startswith("thin") and not err:
+        if "thin" in scenario and not err:
             have = sorted(int(buf[i, 0, 0]) for i in range(buf.shape[0]) if buf[i, 0, 0] >= 0)
-            deep = scenario == "thin_escape"
+            deep = scenario.endswith("escape")
             lo_, hi_ = (sh.lo, sh.hi) if deep else (sh.tlo, sh.thi)
             assert have == list(range(lo_, hi_)), (have, lo_, hi_)
             assert calls["thin"] == pkg._abi.SLAB_THIN_HALO and calls["slab"][1] == sh.tlo
@@ -333,7 +352,8 @@ def _fake_worker(rank, world, port, scenario, out_dir):
 
 
 @pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails", "thin", "thin_escape",
-                                      "step_ok", "step_begin_fails", "step_end_fails"])
+                                      "step_ok", "step_begin_fails", "step_end_fails", "emit_fails",
+                                      "thin_alias_nothing_below_escape", "step_thin_alias_nothing_below_escape"])
 def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
     (nobody is left waiting in the all-gather); quirk Q1 crossing the slab boundary is refused exactly when a rank
@@ -348,10 +368,18 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
         assert "synthetic step_begin failure" in rows[1][0]
     elif scenario == "step_end_fails":
         assert all("cuberille_step_end failed on rank(s) [0]" in r[0] for r in rows)     # close_steps: raised everywhere
-    elif scenario in ("ok", "alias_nothing_below", "thin", "thin_escape", "step_ok"):
+    elif scenario == "emit_fails":
+        # (round-4 advisor finding) no hand-over, one rank's emit fails: the closing gather raises it on every rank
+        assert all("cuberille_emit failed on rank(s) [1]" in r[0] for r in rows)
+        assert "synthetic emit failure" in rows[1][0]
+    elif scenario in ("ok", "alias_nothing_below", "thin", "thin_escape", "step_ok", "thin_alias_nothing_below_escape",
+                      "step_thin_alias_nothing_below_escape"):
+        # (the last two -- round-4 advisor finding: a rank whose buffer starts in empty space, flagged but without a source
+        #  anywhere below, AND whose walks left the thin halo: its escapes travel in a second gather, every rank fetches the
+        #  deep halo, the rank walks them again and the step ends in the same mesh; synchronous and resumed one-wait step)
         assert rows[0][0] == "" and rows[1][0] == ""
         assert rows[0][1] == "(0,)" and rows[1][1] == "(100,)"
-        if scenario.startswith("thin"):                    # 3 + 3 slices around the owned range, flagged as a thin slab
+        if "thin" in scenario:                    # 3 + 3 slices around the owned range, flagged as a thin slab
             assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 17, 20, 40)"
         else:
             assert rows[0][2] == "(40, 0, 0, 20)" and rows[1][2] == "(40, 12, 20, 40)"

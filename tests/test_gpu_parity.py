@@ -1183,10 +1183,12 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
         nz, ny, nx = vox.shape
         prm = pkg.make_params(iso, **kw)
         ex = pkg.Extractor(0)
+        thin = "thin_halo" in options
         for o in options:
             name, _, value = o.partition("=")
-            ex.debug_option(name, int(value or 1))
-        sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm)
+            if name != "thin_halo":
+                ex.debug_option(name, int(value or 1))
+        sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm, thin_halo=thin)
         buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.from_numpy(vox[:1]).dtype, device="cuda:0")
         buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vox[sh.z0:sh.z1]).cuda()      # owned slices only
         first = sh.extract(buf, prm)
@@ -1217,7 +1219,7 @@ def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
                                   "marschner_lobb_stacked", "ghost_lowest_occupied", "ghost_source_in_the_halo",
                                   "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source", "nothing_occupied_below",
                                   "source_in_the_halo_dense_count", "source_in_the_halo_ragged_dense_count",
-                                  "ghost_source_below_the_buffer_dense_count"])
+                                  "ghost_source_below_the_buffer_dense_count", "nothing_occupied_below_thin_halo_escaping_walks"])
 def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case):
     """Quirk Q1 (txx:139-141 before 156-161) when the run of empty slices contains a slab boundary: the rank above
     re-uses vertices the rank below created.  Real processes over gloo on this box's GPU: the source slice's inside
@@ -1232,6 +1234,16 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         vox[10, 4, 3] = 255
         vox[40, 3, 3] = 255
         iso, world = 128, 3
+    elif case == "nothing_occupied_below_thin_halo_escaping_walks":
+        # (round-4 advisor finding) a THIN halo, rank 1's buffer starts in empty space (slices 29..32; its first occupied
+        # slice 33 raises the "source below my buffer?" flag, nobody below holds one) AND its walks -- long steps, no
+        # relaxation -- leave the thin halo: the flag no longer closes the gate, so the blind walk runs and escapes; the
+        # escapes must still reach every rank (a second small gather), the deep halo must be fetched and the walks redone
+        rng = np.random.default_rng(17)
+        vox = np.zeros((64, 12, 70), dtype=np.uint8)
+        vox[33:45] = (rng.random((12, 12, 70)) < 0.3) * 255
+        iso, world = 128, 2
+        kw.update(step=0.6, relax=1.0)
     elif case == "nothing_occupied_below":
         # rank 1's first occupied slice (40) has only empty slices below it in its buffer (from 24 on) and rank 0 holds
         # nothing at all: the count raises its "source below my buffer?" flag, the rows of the ranks below answer it on the
@@ -1281,13 +1293,15 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
         kw["threshold"] = 0.002
     ref = oracle.run(vox, iso, **kw)
     closed_pts, _ = oracle.closed_form_counts(vox, iso)
-    assert (len(ref.points) < closed_pts) == (case not in ("ghost_lowest_occupied", "nothing_occupied_below"))    # the reference really re-uses vertices
+    assert (len(ref.points) < closed_pts) == (case not in ("ghost_lowest_occupied", "nothing_occupied_below",
+                                                           "nothing_occupied_below_thin_halo_escaping_walks"))    # the reference really re-uses vertices
     np.save(str(tmp_path / "vol.npy"), vox)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ("count_variant=34",) if case.endswith("dense_count") else ()
+    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ("count_variant=34",) if case.endswith("dense_count") else \
+        ("thin_halo",) if "thin_halo" in case else ()
     mp.spawn(_q1_worker, args=(world, port, str(tmp_path / "vol.npy"), iso, kw, str(tmp_path), options), nprocs=world, join=True)
 
     class M:
@@ -1298,7 +1312,11 @@ def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case
     m.points, m.cells = np.load(str(tmp_path / "gp2.npy")), np.load(str(tmp_path / "gc2.npy"))     # after the blind steps
     assert_same_mesh(m, ref)
     stats = [eval(str(np.load(str(tmp_path / ("stats%d.npy" % r)))[0])) for r in range(world)]
-    if case == "nothing_occupied_below":
+    if "escaping_walks" in case:
+        # the walks really left the thin halo, on rank 1, in every step; the deep halo came each time
+        assert all(st["escaped"] > 0 and st["deep_halo_fetched"] for st in stats[1]), stats
+        assert all(st["deep_halo_fetched"] for st in stats[0]), stats
+    elif case == "nothing_occupied_below":
         # every step one collective (the row all-gather), the blind ones with the rehearsal's two host waits (gloo stages
         # the rows through the host; RCCL: one)
         assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank), stats
@@ -2181,3 +2199,60 @@ def test_warm_up_and_host_mesh(pkg, oracle, volumes):
     f.SetIsoSurfaceValue(128)
     f.Update()
     assert_same_mesh(f.GetOutput(), oracle.run(volumes("fuel.mha").voxels, 128))
+
+
+def test_warm_up_leaves_a_live_count_and_mesh_alone(pkg, oracle, volumes):
+    """Advisor finding (round 4): cuberille_warm_up(img) for a LARGER image on a context that holds a count or a mesh must not
+    move the workspace under it (DevBuf::reserve frees, then allocates): everything that reads the count's tables and the bit
+    volume afterwards -- the bits, the slice's bit plane on the device, the plane of ids, the emit behind a count -- still
+    gives what it gave before the call.  (The drop-in filter calls warm_up from every SetInput, also after an Update().)"""
+    import torch
+    ex = pkg.Extractor(0)
+    try:
+        vol = volumes("nucleon.mha")
+        nx, ny, nz = vol.dims
+        desc = pkg.make_desc(np.uint8, vol.dims)
+        prm = pkg.make_params(140, triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+        ref = oracle.run(vol.voxels, 140, triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+        big = pkg.make_desc(np.float32, (320, 320, 320))          # every workspace buffer would have to grow
+        dev = torch.from_numpy(vol.voxels).cuda()
+        torch.cuda.synchronize()
+        # (1) between a count and its emit
+        n_p, n_c = ex.count(dev.data_ptr(), desc, prm)
+        assert (n_p, n_c) == (len(ref.points), len(ref.cells))
+        bits_before = ex.debug_bits(vol.dims).copy()
+        ex.warm_up(big)
+        assert np.array_equal(ex.debug_bits(vol.dims), bits_before)
+        # (the plane of ids is defined for a slice with nothing occupied above it: the top corners of its inside voxels are
+        #  all vertices there)
+        zmid = int(np.nonzero((vol.voxels >= 140).any(axis=(1, 2)))[0].max())
+        ptr, n = ex.slice_bits_device(zmid)
+        W = (nx + 63) // 64
+        plane = torch.empty(n, dtype=torch.int64, device="cuda")
+        from midas_journal_740_amd.distributed import _words_view
+        plane.copy_(_words_view(ptr, n, plane.device))
+        torch.cuda.synchronize()
+        assert np.array_equal(plane.cpu().numpy().view(np.uint64).reshape(ny, W), bits_before.reshape(nz, ny, W)[zmid])
+        ex.emit(0)
+        assert_same_mesh(ex.download(), ref)
+        # (2) behind a finished mesh
+        ex.warm_up(big)
+        assert np.array_equal(ex.debug_bits(vol.dims), bits_before)
+        ids = torch.empty((nx + 1) * (ny + 1), dtype=torch.int64, device="cuda")
+        pts = torch.zeros(((nx + 1) * (ny + 1), 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ex.alias_plane_device(zmid, ids.data_ptr(), pts.data_ptr())
+        torch.cuda.synchronize()
+        got = ids.cpu().numpy()
+        live = got >= 0
+        assert live.any() and got[live].max() < n_p
+        # the plane's positions are the mesh's points under those ids
+        assert np.array_equal(pts.cpu().numpy()[live].view(np.uint32), ref.points[got[live]].view(np.uint32))
+        assert_same_mesh(ex.mesh_host(), ref)
+        # the next extraction (of the larger image's size class) grows the workspace itself
+        v2 = volumes("hydrogenAtom.mha")
+        ex.extract_host(v2, pkg.make_params(15, triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100))
+        assert_same_mesh(ex.download(), oracle.run(v2.voxels, 15, triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95,
+                                                   max_steps=100))
+    finally:
+        ex.close()
