@@ -404,10 +404,14 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         with guard("the start of the process group"):
+            import datetime
+            # (the collectives' own limit: torch's watchdog ends a rank whose RCCL collective has not completed by then,
+            #  naming the collective; the StepMonitor of the driver says earlier, and in the path's own words, who waits where)
+            limit = datetime.timedelta(seconds=max(2 * args.step_timeout, 120)) if args.step_timeout > 0 else None
             if rehearsal:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
             else:
-                dist.init_process_group("nccl", device_id=device)
+                dist.init_process_group("nccl", device_id=device, timeout=limit)
     pkg = graft.load_package()
     # the library is built by __graft_entry__.build(); here only make sure it exists, and never let
     # several ranks run the compiler on the same output at once
@@ -434,8 +438,10 @@ def main():
     #  source slices between the ranks, two more small exchanges per step)
     prm = pkg.make_params(iso, triangles=True, project=not args.no_project, threshold=thr, step=0.25, relax=0.95,
                           max_steps=50)
+    mon_timeout = args.step_timeout if (world > 1 and args.step_timeout > 0) else None
     sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
-                          device_offsets=not args.host_offsets, bits_first=args.bits_first and not args.host_offsets)
+                          device_offsets=not args.host_offsets, bits_first=args.bits_first and not args.host_offsets,
+                          step_timeout=mon_timeout, abort_on_timeout=True)
     if not args.no_warm_up:
         ex.warm_up(sh.desc)         # code objects, workspace and staging ring for this rank's buffer: before any step
     period = None if strong else n
@@ -472,7 +478,8 @@ def main():
             fallback = "one-wait step failed on some rank (%s): host-side offsets, full halo" % (why or "another rank")
             args.host_offsets, args.full_halo, args.bits_first = True, True, False
             ex.use_own_stream()
-            sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=False, device_offsets=False)
+            sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=False, device_offsets=False,
+                                  step_timeout=mon_timeout, abort_on_timeout=True)
             res = None
     for _ in range(args.warmup):
         res = sh.extract(buf, prm)
@@ -495,7 +502,8 @@ def main():
             del buf
             sh = ShardedExtractor(ex, (n, n, gnz), dtype, rank, world, params=prm, thin_halo=not args.full_halo,
                                   device_offsets=not args.host_offsets, bounds=bounds,
-                                  bits_first=args.bits_first and not args.host_offsets)
+                                  bits_first=args.bits_first and not args.host_offsets,
+                          step_timeout=mon_timeout, abort_on_timeout=True)
             buf = generate_block(pkg, torch, args.workload, n, sh.lo, sh.hi, period, device)
             buf[:sh.z0 - sh.lo].zero_()
             buf[sh.z1 - sh.lo:].zero_()

@@ -249,13 +249,92 @@ def aliasing_crosses_slabs(occupied, bounds):
     return -1
 
 
+_BITS_GROUPS = {}
+
+
+def _bits_group_of(group):
+    """The second communicator of the bits-first halo: the same ranks as `group`, made once per group and process and
+    re-used by every ShardedExtractor built on it (bench.py builds three: calibration rounds).  torch wants new_group
+    entered by every process of the default group, whatever the ranks: build the first bits_first extractor everywhere."""
+    import torch.distributed as dist
+    key = None if group is None else id(group)
+    if key not in _BITS_GROUPS:
+        ranks = dist.get_process_group_ranks(dist.group.WORLD if group is None else group)
+        _BITS_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+    return _BITS_GROUPS[key]
+
+
+class StepMonitor:
+    """A wall-clock watch over the phases of a multi-rank step.  Under RCCL a collective is only enqueued by the call that
+    names it; what blocks, if a peer never arrives, is the step's one host wait (or torch's own watchdog, minutes later, with
+    a sequence number for a message).  The driver tells the monitor which phase it enters (`enter`: the exchange with which
+    ranks, the row all-gather, the host wait, ...); a daemon thread says ONCE, on stderr, which rank has been in which phase
+    of which step for how long when that exceeds `timeout` seconds -- on every rank that is stuck, so the rank that is
+    missing shows by its absence or by its own, different, phase -- and, abort=True, ends the process with exit code 3 (the
+    launcher then ends the other ranks).  timeout None or 0: nothing is started."""
+
+    def __init__(self, rank, world, timeout=None, abort=False, out=None):
+        import threading
+        self.rank, self.world = rank, world
+        self.timeout = float(timeout) if timeout else 0.0
+        self.abort = bool(abort)
+        self.step = 0
+        self._phase = None            # (text, since)
+        self._said = None
+        self._lock = threading.Lock()
+        self._out = out
+        self._thread = None
+        self._stop = threading.Event()
+
+    def enter(self, text):
+        import time
+        if not self.timeout:
+            return
+        with self._lock:
+            self._phase = (text, time.monotonic())
+        if self._thread is None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def leave(self):
+        if self.timeout:
+            with self._lock:
+                self._phase = None
+
+    def close(self):
+        self._stop.set()
+
+    def message(self, text, seconds):
+        return ("cuberille: rank %d of %d: step %d has been in '%s' for %.0f s (limit %.0f s)%s" % (
+            self.rank, self.world, self.step, text, seconds, self.timeout, " -- giving up (exit 3)" if self.abort else ""))
+
+    def _run(self):
+        import os
+        import sys
+        import time
+        while not self._stop.wait(min(1.0, self.timeout / 4.0)):
+            with self._lock:
+                ph = self._phase
+            if ph is None or ph is self._said:
+                continue
+            waited = time.monotonic() - ph[1]
+            if waited > self.timeout:
+                self._said = ph
+                out = self._out or sys.stderr
+                out.write(self.message(ph[0], waited) + "\n")
+                out.flush()
+                if self.abort:
+                    os._exit(3)
+
+
 class ShardedExtractor:
     """Multi-GPU driver: one instance per rank, wraps one Extractor."""
 
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
                  cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None, close_steps=False,
-                 bits_first=False):
+                 bits_first=False, step_timeout=None, abort_on_timeout=False):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
@@ -279,7 +358,9 @@ class ShardedExtractor:
         close_steps: end every one-wait step in a gather of the ranks' outcomes, so that a failure inside
         cuberille_step_end is raised on every rank (one more collective and host wait per step).
         bounds: the ranks' slices [(z0, z1)] (contiguous, in rank order) instead of slabs of equal thickness -- e.g.
-        balanced_bounds(slice_work()) from a step on a similar volume."""
+        balanced_bounds(slice_work()) from a step on a similar volume.
+        step_timeout (seconds): a StepMonitor watches the phases of every step and says on stderr which rank sits in which
+        exchange, collective or wait for longer than that -- and, abort_on_timeout, ends the process (exit code 3)."""
         from . import _abi
         from .cuberille import make_desc, minimum_halo, required_halo
         self.ex = extractor
@@ -328,8 +409,7 @@ class ShardedExtractor:
         self._bits_group = None
         self._side = None                         # bits_first: side streams and events of the two exchanges
         if self.bits_first:
-            import torch.distributed as dist
-            self._bits_group = dist.new_group(backend=dist.get_backend(group))
+            self._bits_group = _bits_group_of(group)
         self.force_step_path = False              # tests: the one-wait step over CPU tensors and gloo (a stand-in extractor)
         self._lib_stream = None                   # device_offsets: the library's work goes to a torch stream of ours
         self._rows = None
@@ -337,6 +417,11 @@ class ShardedExtractor:
         self._ev = None
         # what the last extract() cost besides kernels (bench.py prints them)
         self.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+        self.monitor = StepMonitor(rank, world, step_timeout, abort_on_timeout)
+
+    def _peers(self, halo, held=0):
+        recvs, sends = halo_transfers(self.nz, self.world, self.rank, halo, held, self.bounds)
+        return "receives from ranks %s, sends to ranks %s" % (sorted({p for p, _, _ in recvs}), sorted({p for p, _, _ in sends}))
 
     # -- halo exchange -------------------------------------------------------------------------------------------
     def _exchange(self, buf, halo, held, slab):
@@ -344,6 +429,7 @@ class ShardedExtractor:
         through two events (RCCL: the library runs on its own stream and thresholds the owned slices meanwhile)."""
         import torch
         import torch.distributed as dist
+        self.monitor.enter("halo exchange, %s slices beyond %s held: %s" % (_pair(halo), _pair(held), self._peers(halo, held)))
         self.stats["halo_bytes"] += halo_bytes(self.nz, self.world, self.rank, self.nx * self.ny * self.itemsize, halo, held,
                                                self.bounds)
         # (self.force_event_path: take the event branch under gloo too -- what the tests on one-GPU boxes set)
@@ -372,9 +458,16 @@ class ShardedExtractor:
     def extract(self, buf, params):
         """buf: device tensor [hi-lo, ny, nx] whose owned slices are valid (written on torch's current stream).
         Runs halo exchange, count, the count all-gather and emit; leaves this rank's mesh part on its device."""
+        self.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+        self.monitor.step += 1
+        try:
+            return self._extract(buf, params)
+        finally:
+            self.monitor.leave()
+
+    def _extract(self, buf, params):
         import torch
         from .cuberille import required_halo
-        self.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
         if self.world == 1:
             # (cuberille_extract_device is the one-wait step with a single rank: from the second extraction on a context
             #  on, everything is launched back to back and the host waits once.  The library runs on a stream of its own:
@@ -433,6 +526,7 @@ class ShardedExtractor:
                 keep = self._exchange(buf, halo, 0, slab)
                 if cuda and slab.voxels_ready_event is None:
                     ls.wait_stream(cur)            # (host-waited exchange: the buffer is ready, order the streams all the same)
+                self.monitor.enter("cuberille_step_begin (sweep, count and vertex phase behind the halo exchange)")
                 ptr, nbytes = self.ex.step_begin(base.data_ptr(), desc, params, slab)
             nw = nbytes // 8
             row = _words_view(ptr, nw, dev)
@@ -443,6 +537,7 @@ class ShardedExtractor:
             nw = row.numel()
         if self._rows is None or self._rows.numel() != self.world * nw or self._rows.device != dev:
             self._rows = torch.empty(self.world * nw, dtype=torch.int64, device=dev)
+        self.monitor.enter("all-gather of the %d ranks' rows (behind the halo exchange: %s)" % (self.world, self._peers(halo)))
         if cuda:
             self._ev[0].record(ls)
             cur.wait_event(self._ev[0])
@@ -464,6 +559,8 @@ class ShardedExtractor:
         res, done, end_failed = None, False, None
         if failed is None:
             try:
+                self.monitor.enter("cuberille_step_end: the one host wait of the step -- for this rank's kernels, the halo exchange "
+                                   "(%s) and the all-gather of %d rows" % (self._peers(halo), self.world))
                 res, done = self.ex.step_end(self._rows.data_ptr(), self.world, self.rank)
                 self.stats["host_syncs"] += 1
             except _abi.CuberilleError as e:
@@ -471,6 +568,7 @@ class ShardedExtractor:
         del keep
         if self.close_steps:
             flag = 1 if end_failed is not None else 0
+            self.monitor.enter("closing gather of the step's outcomes (%d ranks)" % self.world)
             ok = gather_counts(0, 0, dev, self.group, extra=(flag,))
             self.stats["collectives"] += 1
             if cuda:
@@ -542,6 +640,7 @@ class ShardedExtractor:
                 self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev),
                               torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
             sV, sB, ev_vox, ev_halo_vox, ev_bits, ev_halo_bits = self._side
+            self.monitor.enter("bits-first halo: voxels on the main communicator, bit planes on the second (%s)" % self._peers(halo))
             ev_vox.record(cur)
             slab.voxels_ready_event = ev_vox.cuda_event
             slab.halo_ready_event = None
@@ -570,6 +669,7 @@ class ShardedExtractor:
             ptr, nbytes = self.ex.step_count(ev_halo_bits.cuda_event, ev_halo_vox.cuda_event)
             return ptr, nbytes, (keep_v, keep_b)
         # host-waited exchanges (gloo: CPU stand-ins, or several ranks rehearsing on one GPU)
+        self.monitor.enter("bits-first halo, host-waited: sweep, bit planes, voxels (%s)" % self._peers(halo))
         slab.voxels_ready_event = None
         slab.halo_ready_event = None
         if cuda:
@@ -619,6 +719,7 @@ class ShardedExtractor:
             elif resume is not None:
                 n_p, n_c = resume
             else:
+                self.monitor.enter("cuberille_count (sweep and count, a host wait)")
                 n_p, n_c = self.ex.count(base.data_ptr(), desc, params, slab)
                 self.stats["host_syncs"] += 1
             if failed is None and self.check_aliasing and params.emulate_empty_slice_aliasing:
@@ -634,6 +735,7 @@ class ShardedExtractor:
         except _abi.CuberilleError as e:
             failed = e
         del keep
+        self.monitor.enter("all-gather of the %d ranks' counts (host in the loop)" % self.world)
         rows = gather_counts(n_p, n_c, dev, self.group, extra=(
             info.alias_z if info is not None else -1, info.highest if info is not None else -1,
             info.second_highest if info is not None else -1, 0 if failed is None else 1, n_esc))
@@ -664,6 +766,7 @@ class ShardedExtractor:
                         self.stats["host_syncs"] += 1
                     except _abi.CuberilleError as e:
                         failed = e
+                self.monitor.enter("all-gather of the escapes of ranks %s" % [int(r) for r in np.nonzero(late)[0]])
                 rows_e = gather_counts(0, 0, dev, self.group, extra=(n_esc, 0 if failed is None else 1))
                 self.stats["collectives"] += 1
                 self._raise_if_any_failed(rows_e[:, 3], "cuberille_emit_points", failed)
@@ -689,6 +792,7 @@ class ShardedExtractor:
         n_words = self.ny * ((self.nx + 63) // 64)
         n_corners = (self.nx + 1) * (self.ny + 1)
         for r, src, zp, _ in plan:
+            self.monitor.enter("quirk-Q1 hand-over: inside bits of slice %d from rank %d to rank %d" % (zp, src, r))
             # the consumer counts again with the source slice's inside bits at hand: the re-used vertices are no
             # longer created.  A rank that fails here still takes part in every transfer of the plan (nobody waits
             # for a message that never comes); the failure travels in the second gather and is raised everywhere.
@@ -710,6 +814,7 @@ class ShardedExtractor:
                     failed = failed or e
                 del bits
         if plan:
+            self.monitor.enter("second all-gather of the counts (after the quirk-Q1 recount)")
             rows2 = gather_counts(n_p, n_c, dev, self.group, extra=(0 if failed is None else 1,))
             self.counts = rows2[:, :2]
             self._raise_if_any_failed(rows2[:, 2], "cuberille_recount", failed)
@@ -717,6 +822,7 @@ class ShardedExtractor:
         mine = [e for e in plan if e[0] == self.rank and e[3]]
         serve = [e for e in plan if e[1] == self.rank and e[3]]
         planes, res = None, None
+        self.monitor.enter("cuberille_emit (and the quirk-Q1 planes it waits for: %s)" % ([(e[1], e[2]) for e in mine] or "none"))
         try:
             if mine:
                 # ids and final positions of the vertices under the (x, y) corner keys of the source slice's top plane
@@ -752,6 +858,7 @@ class ShardedExtractor:
         # one, a rank whose emit fails alone (out of memory for its part of the mesh, say) must not leave the others on
         # their way into the next step's collectives (round-4 advisor finding).  This is the protocol with the host in
         # the loop: one more small gather does not change what it costs.
+        self.monitor.enter("closing gather of the step's outcomes (%d ranks)" % self.world)
         ok = gather_counts(0, 0, dev, self.group, extra=(0 if failed is None else 1,))
         self.stats["collectives"] += 1
         self._raise_if_any_failed(ok[:, 2], "cuberille_emit", failed)

@@ -236,6 +236,9 @@ def _fake_worker(rank, world, port, scenario, out_dir):
             calls["thin"] = int(slab.flags)
             if scenario == "fail" and rank == 1:
                 raise pkg._abi.CuberilleError(pkg._abi.ERR_HALO, "synthetic failure")
+            if scenario == "slow_peer" and rank == 1:
+                import time
+                time.sleep(2.5)                  # rank 0 sits in the count all-gather meanwhile
             return 100 + rank, 7 * (rank + 1)
 
         def slab_info():
@@ -315,7 +318,9 @@ def _fake_worker(rank, world, port, scenario, out_dir):
         #  "recount_fails", taken up to the consumer's recount, which fails: every rank must raise, none may hang)
         sh = D.ShardedExtractor(fake, (nx, ny, nz), np.float32, rank, world, params=prm,
                                 cross_slab_aliasing=scenario == "recount_fails", thin_halo="thin" in scenario,
-                                close_steps=scenario == "step_end_fails")
+                                close_steps=scenario == "step_end_fails", step_timeout=1.0 if scenario == "slow_peer" else None)
+        if scenario == "slow_peer":
+            sh.monitor._out = open(os.path.join(out_dir, "monitor%d.txt" % rank), "w")
         sh.force_step_path = scenario.startswith("step")
         assert sh.halo == 8 and (sh.lo, sh.hi) == D.buffer_range(nz, sh.z0, sh.z1, 8)
         assert sh.thin == ((3, 3) if "thin" in scenario else None)
@@ -352,7 +357,7 @@ def _fake_worker(rank, world, port, scenario, out_dir):
 
 
 @pytest.mark.parametrize("scenario", ["ok", "fail", "alias", "alias_nothing_below", "recount_fails", "thin", "thin_escape",
-                                      "step_ok", "step_begin_fails", "step_end_fails", "emit_fails",
+                                      "step_ok", "step_begin_fails", "step_end_fails", "emit_fails", "slow_peer",
                                       "thin_alias_nothing_below_escape", "step_thin_alias_nothing_below_escape"])
 def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
     """World size 2 over gloo: id offsets from the gathered counts; a failure on one rank is raised on every rank
@@ -373,7 +378,12 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
         assert all("cuberille_emit failed on rank(s) [1]" in r[0] for r in rows)
         assert "synthetic emit failure" in rows[1][0]
     elif scenario in ("ok", "alias_nothing_below", "thin", "thin_escape", "step_ok", "thin_alias_nothing_below_escape",
-                      "step_thin_alias_nothing_below_escape"):
+                      "step_thin_alias_nothing_below_escape", "slow_peer"):
+        if scenario == "slow_peer":
+            # the StepMonitor of the rank that waits says where it waits, once; the slow rank itself was in its count
+            said = [open(str(tmp_path / ("monitor%d.txt" % r))).read() for r in range(2)]
+            assert said[0].count("\n") == 1 and "rank 0 of 2: step 1 has been in 'all-gather of the 2 ranks' counts" in said[0]
+            assert "cuberille_count" in said[1] and "rank 1 of 2" in said[1]
         # (the last two -- round-4 advisor finding: a rank whose buffer starts in empty space, flagged but without a source
         #  anywhere below, AND whose walks left the thin halo: its escapes travel in a second gather, every rank fetches the
         #  deep halo, the rank walks them again and the step ends in the same mesh; synchronous and resumed one-wait step)
@@ -389,3 +399,63 @@ def test_sharded_extract_collective_outcomes_gloo(tmp_path, scenario):
         assert all("cuberille_recount failed on rank(s) [1]" in r[0] for r in rows)
     else:
         assert all("quirk Q1" in r[0] and "below rank 1" in r[0] for r in rows)
+
+
+@pytest.mark.parametrize("dims,dtype,workload", [((1024, 1024, 1024), np.float32, "sheet"), ((2048, 2048, 2048), np.uint8, "even")])
+def test_eight_rank_plan_of_the_bench_volumes(dims, dtype, workload):
+    """What the first run on a real 8-GPU node will ask of the plan, checked without one: ShardedExtractor at world = 8 for
+    configs[3] (1024^3 float32, the sheet of the Marschner-Lobb field in a sixth of the slices: balanced cuts with slabs of
+    ~28 slices in the middle) and configs[4] (2048^3 uint8), equal and balanced cuts, thin and full halo.  Every slice of every
+    halo arrives exactly once, from its owner, and every receive has its send -- for the thin exchange of a step and for the
+    deep fetch behind an escaped walk (held = thin); buffers, windows and byte counts add up; a rank's buffer fits its GPU."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from midas_journal_740_amd import distributed as D
+    nx, ny, nz = dims
+    world = 8
+    prm = pkg.make_params(0.5 if dtype == np.float32 else 128, triangles=True, project=True,
+                          threshold=0.002 if dtype == np.float32 else 0.5, step=0.25, relax=0.95, max_steps=50)
+    work = np.full(nz, 0.8)
+    if workload == "sheet":
+        work[430:594] += 10.0
+    item = np.dtype(dtype).itemsize
+    slice_bytes = nx * ny * item
+    for bounds in (None, D.balanced_bounds(work, world)):
+        shs = [D.ShardedExtractor(None, dims, dtype, r, world, params=prm, thin_halo=True, bounds=bounds) for r in range(world)]
+        b = shs[0].bounds
+        assert b[0][0] == 0 and b[-1][1] == nz and all(p[1] == q[0] for p, q in zip(b[:-1], b[1:]))
+        if bounds is not None and workload == "sheet":
+            assert min(z1 - z0 for z0, z1 in b) < 40             # the thin slabs the time model of DESIGN.md is about
+        for sh in shs:
+            assert sh.halo == 8 and sh.thin == (3, 3)
+            assert (sh.lo, sh.hi) == (max(sh.z0 - 8, 0), min(sh.z1 + 8, nz))
+            assert (sh.tlo, sh.thi) == (max(sh.z0 - 3, 0), min(sh.z1 + 3, nz))
+            assert int(sh.desc.dims[2]) == sh.hi - sh.lo and int(sh.thin_desc.dims[2]) == sh.thi - sh.tlo
+            assert (int(sh.thin_slab.z_begin), int(sh.thin_slab.own_z0), int(sh.thin_slab.own_z1)) == (sh.tlo, sh.z0, sh.z1)
+            assert (sh.hi - sh.lo) * slice_bytes < 200e9                       # voxels of a rank's buffer on a 288 GB GPU
+        for halo, held in ((shs[0].thin, 0), (shs[0].halo, shs[0].thin), (shs[0].halo, 0)):
+            sent = set()
+            for r, sh in enumerate(shs):
+                recvs, sends = D.halo_transfers(nz, world, r, halo, held, b)
+                (lo, hi), (hlo, hhi) = D.buffer_range(nz, sh.z0, sh.z1, halo), D.buffer_range(nz, sh.z0, sh.z1, held)
+                got = sorted(z for _, a, c in recvs for z in range(a, c))
+                assert got == list(range(lo, hlo)) + list(range(hhi, hi)), (r, halo, held)
+                for peer, a, c in recvs:
+                    assert b[peer][0] <= a and c <= b[peer][1]
+                assert D.halo_bytes(nz, world, r, slice_bytes, halo, held, b) == len(got) * slice_bytes
+                sent.update((r, peer, a, c) for peer, a, c in sends)
+            for r in range(world):
+                for peer, a, c in D.halo_transfers(nz, world, r, halo, held, b)[0]:
+                    assert (peer, r, a, c) in sent
+        # the planes of the bits-first halo are the same transfers, 1/32 (float32) or 1/8 (uint8) of the bytes
+        wps = ny * ((nx + 63) // 64)
+        assert wps * 8 * 8 * item == slice_bytes
+    # quirk Q1 at eight ranks: a volume whose occupied slices lie in ranks 1 and 6 only -- rank 6's first occupied slice has
+    # only empty slices below it in its buffer, the source is rank 1's highest occupied slice, five ranks down
+    b = [D.slab_range(nz, world, r) for r in range(world)]
+    rows = [[0, 0, -1, -1, -1, 0, 0] for _ in range(world)]
+    rows[1] = [10, 10, -1, b[1][0] + 5, b[1][0] + 4, 0, 0]
+    rows[6] = [10, 10, b[6][0] + 7, b[6][0] + 9, b[6][0] + 8, 0, 0]
+    assert D.alias_plan(rows, b) == [(6, 1, b[1][0] + 5, True)]

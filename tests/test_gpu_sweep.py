@@ -1,0 +1,118 @@
+"""-m gpu: the threshold sweep (txx:139-141: inside <=> !(pixel < iso), in the pixel type) at the sizes where it is a kernel of
+its own -- buffers of 256 MiB and more -- for rows that are NOT whole 64-voxel words and for pointers that are not 16-byte
+aligned (k_classify_span_rows): packed bits against a torch threshold, slice occupancy, counts against the closed form, and one
+such volume byte for byte against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_mesh
+from test_gpu_parity import _closed_form_counts_torch, _host_threads
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(shape, dtype, seed=5):
+    """Smooth blobs + noise in the pixel type (neither empty nor everything), a torch tensor on the GPU, and an iso value."""
+    import torch
+    nz, ny, nx = shape
+    tdt = {np.uint16: torch.int32, np.int16: torch.int16, np.int8: torch.int8, np.uint8: torch.uint8, np.uint32: torch.int64,
+           np.int32: torch.int32, np.float32: torch.float32, np.float64: torch.float64, np.int64: torch.int64,
+           np.uint64: torch.int64}[dtype]
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    z = torch.arange(nz, device="cuda", dtype=torch.float32)[:, None, None]
+    y = torch.arange(ny, device="cuda", dtype=torch.float32)[None, :, None]
+    x = torch.arange(nx, device="cuda", dtype=torch.float32)[None, None, :]
+    field = torch.sin(z * 0.11) + torch.sin(y * 0.07 + 1.0) + torch.sin(x * 0.05 + 2.0)
+    field += (torch.rand(shape, device="cuda", generator=g) - 0.5) * 0.02
+    field.clamp_(-2.99, 2.99)
+    info = np.iinfo(dtype) if np.dtype(dtype).kind in "iu" else None
+    if info is not None:
+        lo, hi = (float(info.min) * 0.9, float(info.max) * 0.9) if np.dtype(dtype).itemsize < 8 else (-2.0 ** 40, 2.0 ** 40)
+        if info.min == 0:
+            lo = 0.0
+        vol = ((field + 3.0) / 6.0 * (hi - lo) + lo).to(torch.float64).round().to(tdt)
+        iso = int(round((lo + hi) / 2.0))
+    else:
+        vol = field.to(tdt)
+        iso = 0.125
+    return vol, iso
+
+
+@pytest.mark.parametrize("dtype,shape,skew", [
+    (np.uint8, (300, 1000, 1000), 0), (np.int8, (1100, 500, 500), 3), (np.uint16, (540, 500, 500), 0),
+    (np.int16, (300, 700, 650), 1), (np.uint32, (280, 500, 500), 0), (np.int32, (70, 1000, 1000), 1),
+    (np.float32, (270, 500, 500), 0), (np.float32, (270, 500, 500), 3), (np.float64, (140, 500, 500), 1),
+    (np.int64, (100, 600, 600), 0), (np.uint64, (100, 600, 600), 1),
+    # slices far shorter than a span's rows (65 slices per span: the occupancy of a word takes the division)
+    (np.uint8, (70000, 3, 1300), 5),
+    # whole-word rows behind a pointer that is not 16-byte aligned take the same kernel
+    (np.float32, (257, 512, 512), 1), (np.uint8, (1025, 512, 512), 7)])
+def test_ragged_span_sweep_every_pixel_type(pkg, extractor, dtype, shape, skew):
+    """k_classify_span_rows<T> for every pixel type, rows of 8 ... 21 words that end inside their last word, the pointer
+    `skew` elements off its allocation: packed inside bits equal a torch threshold (tail bits of every row zero), the slice
+    occupancy equals "any inside voxel in the slice" (with empty slices at both ends and in the middle), counts equal the
+    closed form (txx:139-141, 164-173)."""
+    import torch
+    nz, ny, nx = shape
+    vol, iso = _field(shape, dtype)
+    # empty slices: quirk Q1's occupancy must see them (everything below the iso value)
+    lowest = vol.min()
+    for a, b in ((0, 2), (nz // 2, nz // 2 + 3), (nz - 1, nz)):
+        vol[a:b] = lowest
+    narrow = {np.uint16: torch.int16, np.uint32: torch.int32}
+    dev = vol.to(narrow[dtype]) if dtype in narrow else vol
+    item = np.dtype(dtype).itemsize
+    assert dev.element_size() == item and dev.numel() * item >= (256 << 20)
+    raw = torch.empty(dev.numel() + 16, dtype=dev.dtype, device="cuda")
+    raw[skew:skew + dev.numel()] = dev.reshape(-1)
+    del dev
+    torch.cuda.synchronize()
+    ptr = raw.data_ptr() + skew * item
+    assert nx % 64 != 0 or ptr % 16 != 0
+    inside = vol >= iso
+    want_pts, want_quads = _closed_form_counts_torch(inside)
+    assert 1000 < want_quads
+    res = extractor.extract_device(ptr, pkg.make_desc(dtype, (nx, ny, nz)), pkg.make_params(iso, triangles=False, project=False))
+    assert (int(res.n_points), int(res.n_cells)) == (want_pts, want_quads)
+    W = (nx + 63) // 64
+    words = torch.from_numpy(extractor.debug_bits((nx, ny, nz)).view(np.int64)).cuda()
+    shifts = torch.arange(64, device="cuda", dtype=torch.int64)
+    step = max(1, (1 << 24) // (ny * W * 64))
+    for z0 in range(0, nz, step):
+        bits = ((words[z0:z0 + step, :, :, None] >> shifts) & 1).bool().reshape(-1, ny, W * 64)
+        assert torch.equal(bits[:, :, :nx], inside[z0:z0 + step]), "packed bits differ from the threshold in slices %d.." % z0
+        assert not bits[:, :, nx:].any(), "bits beyond the end of a row in slices %d.." % z0
+    occ = extractor.slice_occupancy(nz)
+    assert np.array_equal(occ != 0, inside.reshape(nz, -1).any(1).cpu().numpy())
+    # the plain sweep (development switch) packs the same words
+    extractor.debug_option("classify_variant", 1)
+    try:
+        res2 = extractor.extract_device(ptr, pkg.make_desc(dtype, (nx, ny, nz)), pkg.make_params(iso, triangles=False, project=False))
+        assert (int(res2.n_points), int(res2.n_cells)) == (want_pts, want_quads)
+        assert torch.equal(torch.from_numpy(extractor.debug_bits((nx, ny, nz)).view(np.int64)).cuda(), words)
+    finally:
+        extractor.debug_option("defaults", 0)
+    del vol, raw, inside, words
+
+
+def test_ragged_1000_wide_volume_matches_oracle(pkg, oracle, extractor):
+    """A volume of the size and shape real data has -- 1000 x 1000 voxels per slice, 300 slices, float32, 1.2 GB: rows of 15 5/8
+    words -- through the production launch shapes (k_classify_span_rows, the count, blind launches from the second call on),
+    byte for byte against the oracle: slices 350 .. 650 of the 1000^3 sphere field of bench.py (configs[2]'s generator and
+    parameters), triangles and projection on.  The band cuts the sphere open at both ends: the reference's open border (Q2)."""
+    import torch
+    n, a, b = 1000, 350, 650
+    vol = pkg.volumes.sphere_sdf(n, a, b, xp=torch, device=torch.device("cuda", 0)).contiguous()
+    # (the generator's z is absolute; the extractor sees a volume of its own with origin 0: same voxels, that is all that matters)
+    torch.cuda.synchronize()
+    desc = pkg.make_desc(np.float32, (n, n, b - a))
+    kw = dict(triangles=1, project=1, threshold=0.05, step=0.25, relax=0.95, max_steps=50)
+    prm = pkg.make_params(0.0, **kw)
+    for _ in range(3):                         # the third call runs blind, sized by the second
+        res = extractor.extract_device(vol.data_ptr(), desc, prm)
+    mesh = extractor.download()
+    ref = oracle.run(vol.cpu().numpy(), 0.0, gradient_threads=_host_threads(), **kw)
+    assert int(res.n_points) == len(ref.points) > 1000000
+    assert_same_mesh(mesh, ref)
+    assert int(res.proj_iterations) == ref.info["proj_iterations"]
+    del vol
