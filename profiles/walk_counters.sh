@@ -7,10 +7,14 @@
 # rocprofv3 lists for the device are asked for.
 TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/walk_$TAG
-mkdir -p "$OUT"
+# raw rocprofv3 output stays in /tmp (tens of MiB per pass; gpurun_out/ carries 64 MiB at most): the summary is what is kept
+OUT=/tmp/walk_$TAG
+LOGS=$R/gpurun_out/walk_$TAG
+mkdir -p "$OUT" "$LOGS"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
+timeout -k 10 120 rocprofv3 -L > "$LOGS/counters_available.txt" 2>&1 || echo "rocprofv3 -L failed or timed out"
+cp "$LOGS/counters_available.txt" "$OUT/counters_available.txt"
+echo "counters listed: $(wc -l < "$LOGS/counters_available.txt") lines"
 have() { grep -qw "$1" "$OUT/counters_available.txt"; }
 GROUPS_=(
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
@@ -31,8 +35,8 @@ for G in "${GROUPS_[@]}"; do
   [ -z "$ASK" ] && continue
   for SHAPE in "512 8192 256" "2048 2048 256"; do
     D="$OUT/g${i}_$(echo $SHAPE | tr ' ' 'x')"
-    rocprofv3 --kernel-trace --kernel-include-regex k_project --pmc $ASK --output-format csv -d "$D" -o p -- python3 "$R/profiles/walk_row_width.py" $SHAPE 1 > "$D.log" 2> "$D.err" \
-      && echo "group $i ($ASK) on $SHAPE done" || { echo "group $i ($ASK) on $SHAPE FAILED (see $D.err)"; FAIL=1; }
+    timeout -k 10 240 rocprofv3 --kernel-trace --kernel-include-regex k_project --pmc $ASK --output-format csv -d "$D" -o p -- python3 "$R/profiles/walk_row_width.py" $SHAPE 1 > "$D.log" 2> "$D.err" \
+      && echo "group $i ($ASK) on $SHAPE done" || { echo "group $i ($ASK) on $SHAPE FAILED or timed out"; tail -5 "$D.err"; cp "$D.err" "$LOGS/"; FAIL=1; }
   done
 done
 python3 - "$OUT" "$R/gpurun_out/${TAG}_walk_row_width_counters.txt" <<'PY'
@@ -57,5 +61,4 @@ with open(dst, "w") as o:
         o.write("# " + open(f).read().strip().replace("\n", "\n# ") + "\n")
 print(open(dst).read())
 PY
-[ "$FAIL" = 0 ] && rm -rf "$OUT"/g*_*x*/ 
 exit $FAIL

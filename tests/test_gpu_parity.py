@@ -420,7 +420,9 @@ def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, e
         assert bounds[0][0] == 0 and bounds[-1][1] == 40 and all(b > a for a, b in bounds)
         assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
     elif mode.startswith("step"):
-        assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 2) for st in stats), stats
+        # (one collective per step; where walks escape: the row all-gather, the count all-gather of the synchronous protocol
+        #  that takes over, and its closing gather)
+        assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 3) for st in stats), stats
         if mode.endswith("_bits"):
             # a bit plane per halo slice: 1/8 of the uint8 voxels' bytes here (1/32 for float32), rounded up to words per row
             wps = 40 * ((104 + 63) // 64)
