@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# CUBERILLE_LIB: load another build of the same ABI (same-box A/B timing of kernel changes)
+# CUBERILLE_LIB: load another build of the same ABI (same-box A/B timing of kernel changes).  The one environment variable
+# this BINDING reads; the library itself reads none (include/cuberille_hip.h).
 LIB_PATH = os.environ.get("CUBERILLE_LIB") or os.path.join(CSRC, "libcuberille_hip.so")
 
 OK, ERR_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_HALO, ERR_LIMIT, ERR_SOURCE, RETRY = range(9)

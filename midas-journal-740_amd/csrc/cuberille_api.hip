@@ -526,8 +526,22 @@ int count_launch(cuberille_ctx *c, const Gate &gate) {
   HIP_TRY(c, launch_occupancy(c->pixel_type, c->w, c->g, c->tune, s));
   // (the LDS-tiled form pays where most words carry surface -- 2048^3 noise -- and costs where few do: it stages every
   //  row, a sparse block's untiled form skips whole words; the previous extraction's density decides)
-  const int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 3 : 0);
-  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, tiled, s));
+  int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 3 : 0);
+  if (c->tune.count_variant < 0 && !c->haveHistory && c->nwords >= (1u << 22) && c->g.wShift >= 0) {
+    // no previous extraction to go by (round-4 review: a one-shot caller of a dense field paid 2.3 ms for a 1.2 ms count):
+    // a sample of THIS volume's bit volume picks the form -- one small launch and one more wait, on a context's first
+    // extraction only, which waits for its counts anyway.  (Totals::iters carries the sample: the walk, which counts its
+    // passes there, is a long way off; zeroed again behind the read.)
+    u64 *slot = &c->w.totals->iters;
+    HIP_TRY(c, launch_density_probe(c->w, c->g, c->nwords, slot, s));
+    HIP_TRY(c, hipMemcpyAsync(&c->hostTotals->iters, slot, sizeof(u64), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(slot, 0, sizeof(u64), s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const u64 v = c->hostTotals->iters;
+    const u64 mixed = v & 0xffffffffull, sampled = v >> 32;
+    if (sampled && mixed * 4 >= sampled) tiled = 3;
+  }
+  HIP_TRY(c, launch_count(c->w, c->g, c->nwords, c->prm.q1, gate, tiled, c->tune.count_no_fold, s));
   if (!c->lightTiming) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   return CUBERILLE_OK;
 }
@@ -1467,7 +1481,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split)
+  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split) OPT(count_no_fold)
 #undef OPT
   return false;
 }

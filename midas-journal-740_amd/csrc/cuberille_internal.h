@@ -57,7 +57,8 @@ struct Totals {        // device-resident, zeroed before every count, mirrored t
   // -1: none; written by k_block_scan): the first occupied slice of the counted range -- the one such a flag is about --
   // and the highest and second-highest occupied OWNED slices (cuberille_slab_status has the same three for the host)
   int aliasZ, topZ, top2Z;
-  u32 reserved;
+  u32 ticket;          // count blocks that have published their totals (the last one scans them where the count kernel does
+                       // the block scan itself: launches whose blocks are all resident at once)
 };
 
 enum {
@@ -138,7 +139,9 @@ struct Tuning {
   // the walk: vertices per batch (0: 64 when the launch leaves wave slots empty, else 128), waves in the grid, idle lanes
   // at which a wave refills (0: 16; 64 = only when empty, where the previous extraction's walks took under four passes
   // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass
-  int proj_chunk = 0, proj_waves = 16384, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
+  // (proj_waves 0: 16 384, or 65 536 waves dealing batches of 64 where walks are short -- see launch_project)
+  int proj_chunk = 0, proj_waves = 0, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
+  int count_no_fold = 0;      // 1: the block scan always as a launch of its own (A/B of the scan folded into small count launches)
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };
 
@@ -165,13 +168,14 @@ hipError_t launch_classify(int pixel_type, const Workspace &w, const Grid &g, co
                            hipStream_t s);
 hipError_t launch_occupancy(int pixel_type, const Workspace &w, const Grid &g, const Tuning &t, hipStream_t s);
 hipError_t launch_occupancy_range(const Workspace &w, const Grid &g, int z0, int z1, hipStream_t s);
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s);
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, int noFold, hipStream_t s);
 hipError_t launch_heads(const Workspace &w, const Grid &g, u64 totV, u64 totQ, int dyn, hipStream_t s);
 hipError_t launch_emit_points(const Workspace &w, const Grid &g, const Geo &geo, int q1, u64 nV, u32 nVertexWords,
                               const Tuning &t, int dyn, hipStream_t s);
 hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, int q1, u64 pointOffset, u64 nQ,
                              const u64 *extIds, const Totals *rows, int nRanks, int rank, int dyn, hipStream_t s);
 hipError_t launch_slice_prefix(const Workspace &w, const Grid &g, u64 *out, hipStream_t s);
+hipError_t launch_density_probe(const Workspace &w, const Grid &g, size_t nwords, u64 *out, hipStream_t s);
 hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64 pointOffset, u64 *idsOut, float *ptsOut,
                               hipStream_t s);
 hipError_t launch_recursive_gaussian(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const double coef[3][2][20],

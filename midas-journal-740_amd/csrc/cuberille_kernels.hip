@@ -1054,6 +1054,91 @@ __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independe
   return (u64)wave_inclusive_sum((u32)v) | ((u64)wave_inclusive_sum((u32)(v >> 32)) << 32);
 }
 
+// The block scan as the epilogue of the LAST count block to publish its totals (k_block_scan's work for launches of at most
+// FOLD_MAX_BLOCKS blocks: all of them resident at once, so the wave that lingers for its ticket holds nobody's place; beyond
+// that a lingering block per round costs more than the 9 us launch -- round 2 measured it -- and k_block_scan stays).
+// Hand-off (MI355X guide, inter-workgroup visibility): every block's wave 0 stores its total (and g0pre) write-through
+// (agent-scope atomic stores = sc1), waits for them (vmcnt(0)), then adds to the ticket; the block whose add returns
+// nblk - 1 acquires at agent scope and reads every total with agent-scope loads.  The err and nVertexWords words are only ever
+// touched by device-scope atomics.
+constexpr u32 FOLD_MAX_BLOCKS = 1280;
+template <int NT>
+__device__ void block_scan_tail(const u64 *blockTot, u64 *__restrict__ blockBase, u32 nblk, size_t g0, Totals *tot, const Gate &gate,
+                                const u32 *__restrict__ sliceOcc, const Grid &g, u64 *waveSum /* NT / 64 LDS words */,
+                                int *occ3 /* 3 LDS ints */) {
+  constexpr int NWAVES = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cz0 = g.cz0, oz0 = g.oz0, oz1 = g.oz1;
+  if (g.gnz != (long long)g.nzb) {
+    // a SLAB's row: first occupied slice of the counted range, highest and second-highest occupied owned slice (row_flags)
+    auto wave_min = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o < v ? o : v; } return v; };
+    auto wave_max = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o > v ? o : v; } return v; };
+    if (tid == 0) { occ3[0] = 0x7fffffff; occ3[1] = -1; occ3[2] = -1; }
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (int z = cz0 + tid; z < oz1; z += NT)
+      if (sliceOcc[z]) {
+        lo = z < lo ? z : lo;
+        if (z >= oz0) hi = z;
+      }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0 && lo != 0x7fffffff) atomicMin(&occ3[0], lo);
+    if (lane == 0 && hi >= 0) atomicMax(&occ3[1], hi);
+    __syncthreads();
+    const int top = occ3[1];
+    int second = -1;
+    for (int z = oz0 + tid; z < top; z += NT)
+      if (sliceOcc[z]) second = z;
+    second = wave_max(second);
+    if (lane == 0 && second >= 0) atomicMax(&occ3[2], second);
+    __syncthreads();
+    if (tid == 0) {
+      tot->aliasZ = occ3[0] == 0x7fffffff ? -1 : (int)(g.zglob0 + occ3[0]);
+      tot->topZ = top < 0 ? -1 : (int)(g.zglob0 + top);
+      tot->top2Z = occ3[2] < 0 ? -1 : (int)(g.zglob0 + occ3[2]);
+    }
+  } else if (tid == 0) {
+    tot->aliasZ = tot->topZ = tot->top2Z = -1;
+  }
+  u64 runV = 0, runQ = 0;
+  for (u32 base = 0; base < nblk; base += NT) {
+    const u32 b = base + tid;
+    const u64 v = b < nblk ? __hip_atomic_load(&blockTot[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const u64 incl = wave_inclusive_sum2(v);
+    if (lane == 63) waveSum[wv] = incl;
+    __syncthreads();
+    u64 before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) { const u64 t = waveSum[w]; all += t; if (w < wv) before += t; }
+    const u64 excl = before + incl - v;                            // halves stay below 2^32: no carry crosses
+    const u64 bV = runV + (excl & 0xffffffffull), bQ = runQ + (excl >> 32);
+    if (b < nblk) {
+      blockBase[2 * (size_t)b] = bV;
+      blockBase[2 * (size_t)b + 1] = bQ;
+      if (g0 > 0 && (g0 >> COUNT_LG) == b) {
+        const u64 in = __hip_atomic_load(&tot->g0pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot->V0 = bV + (in & 0xffffffffull);
+        tot->Q0 = bQ + (in >> 32);
+      }
+    }
+    runV += all & 0xffffffffull;
+    runQ += all >> 32;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    tot->totV = runV;
+    tot->totQ = runQ;
+    if (gate.on) {
+      u32 err = __hip_atomic_load(&tot->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 nvw = __hip_atomic_load(&tot->nVertexWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (runV > gate.coverV || runQ > gate.coverQ || nvw > gate.coverVW) err |= (u32)ERRF_CAPACITY;
+      if (err & (u32)ERRF_CAPACITY) atomicOr(&tot->err, (u32)ERRF_CAPACITY);
+      tot->go = (err & (u32)(ERRF_ALIAS_UNKNOWN | ERRF_CAPACITY)) == 0 ? 1u : 0u;      // (see k_block_scan)
+    }
+  }
+}
+
 // TILED: every bit row the block reads -- the rows of its own 2048 words, one row before and after, the same of the
 // slices below and above -- is first copied into LDS as three contiguous, coalesced ranges (rows are consecutive in the
 // flat order; ~54-58 KB), and the face tests and the corner logic read the copy: the 27 rows of a surface word are
@@ -1067,12 +1152,16 @@ constexpr int COUNT_ZRUN = 8;                             // blocks a workgroup 
 
 // (untiled, 5 waves per SIMD: 96 VGPRs and a 48-byte spill beat 103 VGPRs at 4 waves, 0.135 vs 0.144 ms; 6 waves spill
 //  too much)
-template <int MODE, bool TILED, int NT>   // MODE 0 in the library; 2: no block scan, 4: no corner logic (microbench)
+template <int MODE, bool TILED, int NT, bool FOLD = false>   // MODE 0 in the library; 2: no block scan, 4: no corner logic (microbench)
 __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const u64 *__restrict__ bits, const u32 *__restrict__ occ, Grid g,
                                                size_t nwords, int q1, u32 *__restrict__ prefix, u64 *__restrict__ segPre,
-                                               u64 *__restrict__ blockTot, u32 *__restrict__ vqueue,
-                                               Totals *__restrict__ tot, int zrun) {
+                                               u64 *blockTot, u32 *__restrict__ vqueue,
+                                               Totals *tot, int zrun, u64 *__restrict__ blockBase, Gate gate, int foldArg) {
+  const int fold = FOLD ? foldArg : 0;          // FOLD: the block scan as the last block's epilogue (fold = blocks of the launch)
   __shared__ u32 cnt[COUNT_WB];                 // V | Q<<16 per word (<= 512 and <= 384: the packed scan cannot carry)
+  __shared__ u64 tailSum[FOLD ? NT / 64 : 1];   // fold: the last block's scan of the block totals
+  __shared__ int tailOcc[3];
+  __shared__ int lastBlock;
   __shared__ unsigned short queue[COUNT_WB];
   __shared__ u64 segTot[COUNT_WB / 64];
   __shared__ u64 segVW[COUNT_WB / 64];          // per segment: which of its 64 words create vertices
@@ -1092,7 +1181,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
     const u32 blk = zrun ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x;
     const size_t w0 = (size_t)blk * COUNT_WB;
     if (w0 >= nwords) break;                       // (the same for every thread)
-    if (tid == 0) { nQueued = 0; g0InSeg = 0; }
+    if (tid == 0) { nQueued = 0; g0InSeg = 0; lastBlock = 0; }
     long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
     int slot = 1;                                  // ... and which third of the tile holds the block's own slice
     if (TILED) {
@@ -1194,7 +1283,10 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       for (int c = 0; c < 8; c++) nV += popc64(w.C[c]);
       cnt[i] |= (u32)nV;
     }
-    if (errBits) atomicOr(&tot->err, errBits);
+    if (errBits) {
+      atomicOr(&tot->err, errBits);
+      if (fold) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (on its way before this block's ticket, behind the barrier)
+    }
     __syncthreads();
     for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
       const size_t gi = w0 + sg * 64 + lane;
@@ -1229,9 +1321,14 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       if (lane < COUNT_WB / 64 && (seg << 6) < nwords) segPre[seg] = excl;
       if (g0 > 0 && (g0 >> COUNT_LG) == blk && lane == (int)((g0 >> 6) & (COUNT_WB / 64 - 1))) {
         const u32 in = g0InSeg;
-        tot->g0pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
+        const u64 pre = excl + ((u64)(in & 0xffffu) | ((u64)(in >> 16) << 32));
+        if (fold) __hip_atomic_store(&tot->g0pre, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else tot->g0pre = pre;
       }
-      if (lane == COUNT_WB / 64 - 1) blockTot[blk] = incl;
+      if (lane == COUNT_WB / 64 - 1) {
+        if (fold) __hip_atomic_store(&blockTot[blk], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // write-through
+        else blockTot[blk] = incl;
+      }
     }
     if (vqueue) {
       __syncthreads();
@@ -1239,6 +1336,24 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
         const u64 vm = segVW[sg];
         if ((vm >> lane) & 1ull)
           vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
+      }
+    }
+    if (fold) {
+      // the ticket, behind everything else of the block (the other waves are gone by the time it returns): wave 0's stores
+      // have landed (vmcnt(0)), then one agent-scope add; the block that draws the last ticket scans the totals
+      if (wv == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u32 t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&tot->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __shfl(t, 0, 64);
+        if (lane == 0 && t == (u32)fold - 1u) lastBlock = 1;
+      }
+      __syncthreads();
+      // (lastBlock is reset at the top of a workgroup's NEXT block, unguarded: the workgroup that reads 1 here has no next
+      //  block -- the last ticket says every block of the launch is done -- and elsewhere 0 is written over 0)
+      if (lastBlock) {                               // (the same for every thread)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        block_scan_tail<NT>(blockTot, blockBase, (u32)fold, g0, tot, gate, occ, g, tailSum, tailOcc);
       }
     }
   }   // the workgroup's next block
@@ -2997,7 +3112,10 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       const u64 nwordsAll = nrows * g.W;
       const u64 nspans = (nwordsAll + SPAN_WORDS - 1) / SPAN_WORDS;
       const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;     // two workgroups per CU
-      const unsigned blocks = (unsigned)(nspans < want ? nspans : want);
+      // (the workgroups take the spans in rounds: as many workgroups as fill every round -- 3907 spans of a 1000^3 volume
+      //  are 8 rounds of 489 rather than 7 of 512 and one of 323, whose time is a whole round's)
+      const u64 rounds = (nspans + want - 1) / want;
+      const unsigned blocks = (unsigned)((nspans + rounds - 1) / rounds);
       hipLaunchKernelGGL((k_classify_span_rows<T>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, nwordsAll, g.nx, g.W, (u32)g.ny,
                          iso, isoI, w.sliceOcc);
     } else if (ragged_stream_path(wAll, g, sizeof(T), tn)) {
@@ -3052,13 +3170,44 @@ hipError_t launch_occupancy_range(const Workspace &w, const Grid &g, int z0, int
   return hipGetLastError();
 }
 
-hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, hipStream_t s) {
+// A context's FIRST extraction has no previous one to take the form of its count from: a sample of the bit volume -- every
+// stride-th word of the counted range, a few thousand wave loads -- says how many words hold both inside and outside voxels
+// (every such word has faces along x and creates vertices).  out: mixed words | sampled words << 32, added to.
+__global__ __launch_bounds__(256) void k_density_probe(const u64 *__restrict__ bits, size_t nwords, size_t stride, int nx, int W,
+                                                       u64 *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t * stride;
+  bool mixed = false, live = i < nwords;
+  if (live) {
+    const u64 w = bits[i];
+    // (the last word of a row that ends inside it is full at fewer than 64 bits)
+    const int k = (int)(i % (size_t)W), n = nx - k * 64;
+    const u64 full = n < 64 ? lowmask(n) : ~0ull;
+    mixed = w != 0ull && w != full;
+  }
+  const u64 m = __ballot(mixed), l = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && l) atomicAdd((unsigned long long *)out, (unsigned long long)__popcll(m) | ((unsigned long long)__popcll(l) << 32));
+}
+
+hipError_t launch_density_probe(const Workspace &w, const Grid &g, size_t nwords, u64 *out, hipStream_t s) {
+  const size_t samples = 1u << 18;
+  const size_t stride = nwords / samples > 0 ? (nwords / samples) | 1 : 1;      // (odd: walks through the word columns)
+  const size_t n = (nwords + stride - 1) / stride;
+  const u64 *counted = w.bits + (size_t)g.cz0 * g.ny * g.W;
+  hipLaunchKernelGGL(k_density_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counted, nwords, stride, g.nx, g.W, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1, const Gate &gate, int tiled, int noFold, hipStream_t s) {
   const unsigned blocks = (unsigned)((nwords + COUNT_WB - 1) / COUNT_WB);
   u32 *vq = nwords < 0xffffffffULL ? w.vqueue : nullptr;
   const size_t sliceWords = (size_t)g.ny * g.W;
   // (tiled 3, or 32 + one of the values below: the dense form -- faces and corner logic in one phase, per lattice corner --
   //  where a row is a power of two of words, else the two-phase tile)
   const bool fused = (tiled == 3 || tiled >= 32) && g.wShift >= 0;
+  // the block scan inside the count launch where every count block is resident at once (block_scan_tail)
+  const bool foldable = blocks <= FOLD_MAX_BLOCKS && !noFold;
+  unsigned fold = 0;
   if (tiled == 3) tiled = 1;
   else if (tiled >= 32) tiled -= 32;
   if (tiled && g.W <= TILE_WMAX) {
@@ -3077,15 +3226,23 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
                          w.totals, zrun);
     else
       hipLaunchKernelGGL((k_count<0, true, 512>), dim3(grid), dim3(512), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                         w.blockTot, vq, w.totals, zrun);
+                         w.blockTot, vq, w.totals, zrun, w.blockBase, gate, 0);
   } else if (blocks <= 64)
     // (a handful of blocks -- every volume the reference ships: the kernel's time is a block's latency, two trips through its
     //  loops instead of eight)
-    hipLaunchKernelGGL((k_count<0, false, 1024>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals, 0);
+    if (foldable)
+      hipLaunchKernelGGL((k_count<0, false, 1024, true>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                         w.blockTot, vq, w.totals, 0, w.blockBase, gate, (int)(fold = blocks));
+    else
+      hipLaunchKernelGGL((k_count<0, false, 1024>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                         w.blockTot, vq, w.totals, 0, w.blockBase, gate, 0);
+  else if (foldable)
+    hipLaunchKernelGGL((k_count<0, false, 256, true>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
+                       w.blockTot, vq, w.totals, 0, w.blockBase, gate, (int)(fold = blocks));
   else
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals, 0);
+                       w.blockTot, vq, w.totals, 0, w.blockBase, gate, 0);
+  if (fold) return hipGetLastError();              // (the last count block did the scan)
   const size_t g0 = (size_t)(g.oz0 - g.cz0) * g.ny * g.W;
   const unsigned chunks = blocks > SCAN_CHUNK ? (blocks + SCAN_CHUNK - 1) / SCAN_CHUNK : 1;
   if (chunks > 1) hipLaunchKernelGGL(k_block_partial, dim3(chunks), dim3(1024), 0, s, w.blockTot, blocks);
@@ -3250,10 +3407,18 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   //  the tails of the waves' sequences better: 0.83 -> 0.74 ms there, 0.38 -> 0.33 at 1.6 M; at 11.1 M 128 wins by 2 %)
   //  -- but only once batches of 64 fill the grid: between the two, 0.8 M vertices of a 512^3 sphere, 6170 waves that refill
   //  from their 128 beat 12 340 that cannot, 0.172 against 0.187 ms)
-  const u64 gridWaves = (u64)tn.proj_waves;
+  // (round 5: where walks are SHORT -- waves that refill only when empty, a dense field -- the walk is bound by its gathers, and
+  //  what those cost follows how far apart in the vertex list the waves resident at one time work: counters of the same
+  //  field in rows of 512 and of 2048 voxels, profiles/r5_walk_row_width_counters.txt -- no translation misses; L1 hit rate 80 ->
+  //  68 %, L2 37 -> 24 %, 1.7x the requests beyond L2, twice the latency per request.  A wave of a 16 384-wave launch works
+  //  through 15 batches that lie 2 M vertices apart, and the 4096 resident waves are at different places of their
+  //  sequences; 65 536 waves of batches of 64 take 7: 2048 x 2048 x 256 noise 68 -> 53.5 ps per vertex, and slower again
+  //  with 131 072 (62) or one batch per wave (101: a wave's start costs more than it walks).  Long walks keep 16 384.)
+  const bool shortWalks = tn.proj_refill >= 64;
+  const u64 gridWaves = tn.proj_waves > 0 ? (u64)tn.proj_waves : (shortWalks ? 65536ull : 16384ull);
   const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : 8000000ull;
   u64 chunk = tn.proj_chunk > 0 ? (tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk)
-            : (nPoints <= 64ull * 4096 || (nPoints > 64 * (gridWaves ? gridWaves : 16384) && nPoints < upTo)) ? 64 : 128;
+            : (nPoints <= 64ull * 4096 || (nPoints > 64 * gridWaves && (nPoints < upTo || shortWalks))) ? 64 : 128;
   while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
   u64 nwaves = (nPoints + chunk - 1) / chunk;
   if (gridWaves && nwaves > gridWaves) nwaves = gridWaves;

@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
     fflush(stdout);
   };
 #define KC(MODE, TILED, NT, VQ) hipLaunchKernelGGL((k_count<MODE, TILED, NT>), dim3(blocks), dim3(NT), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
-                                                    w.prefix, w.segPre, w.blockTot, VQ, w.totals, 0)
+                                                    w.prefix, w.segPre, w.blockTot, VQ, w.totals, 0, w.blockBase, Gate{}, 0)
   printf("n %d wavelength %.0f\n", n, wl);
   timeIt([&] { KC(0, false, 256, w.vqueue); }, "untiled: everything");
   timeIt([&] { KC(0, false, 256, (u32 *)nullptr); }, "untiled: no vertex-word queue");
@@ -85,7 +85,7 @@ int main(int argc, char **argv) {
 #define KF(MODE, ZRUN) hipLaunchKernelGGL((k_count_dense<MODE>), dim3(blocks), dim3(512), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
                                                     w.prefix, w.segPre, w.blockTot, w.vqueue, w.totals, ZRUN)
 #define KT(MODE, ZRUN) hipLaunchKernelGGL((k_count<MODE, true, 512>), dim3(blocks), dim3(512), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
-                                                    w.prefix, w.segPre, w.blockTot, w.vqueue, w.totals, ZRUN)
+                                                    w.prefix, w.segPre, w.blockTot, w.vqueue, w.totals, ZRUN, w.blockBase, Gate{}, 0)
   timeIt([&] { KF(0, 0); }, "dense form: everything");
   timeIt([&] { KF(8, 0); }, "dense form: no virtual words");
   timeIt([&] { KF(4, 0); }, "dense form: no corner logic");
