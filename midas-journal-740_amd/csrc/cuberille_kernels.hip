@@ -2722,6 +2722,309 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4, producer form (round 5; the one shape of the refilling walk rounds 2-4 had not tried): in k_project a refill runs the
+// start-cell gather -- twelve row loads, eight site gradients, as many instructions as a pass of the walk, and two memory
+// round trips during which the walking lanes of the wave wait -- for the 16-24 lanes it brings in.  Here ONE wave of the
+// workgroup does nothing else: with all 64 lanes it gathers the start cells of the workgroup's vertices, batch after batch,
+// and leaves each vertex as a ready entry (position, cell, the 24 site-gradient components, the 8 site values) in a ring of
+// RING batches in LDS; the other three waves walk, and a refill is 40 LDS reads.  The workgroup's batches are w, w + NWG, ...
+// of 64 vertices; its walkers take entries in order through an LDS counter (`head`), so they share the stream dynamically.
+// Every wait has an exit: a walker waits for `produced` to cover the entries it claimed -- the producer never waits for a
+// walker that waits for it (a slot is re-used only when every entry of the batch RING back has been copied out, and entries
+// are claimed in order) -- and all spins are bounded (a bug ends in the err word, not in a hung GPU).
+// MODE 0 only (whole volumes and full-halo slabs); same results bit for bit: scheduling does not enter the arithmetic.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct ProducerRing {
+  typedef typename SiteValue<T>::type SV;
+  static constexpr int NV = (int)(sizeof(SV) / 4) * 8;     // dwords of the eight site values
+  static constexpr int NF = 8 + 24 + NV;                  // dwords per entry: idx, x, y, z, kc[3], flags, G, Vd
+  static constexpr int RING = 3;
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 4) void k_project_pw(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+                                                    float *__restrict__ points, u64 nPoints, u64 nGhost, int REFILL,
+                                                    int forceLiteral, Totals *__restrict__ tot, int dyn) {
+  typedef ProducerRing<T> R;
+  typedef typename R::SV SV;
+  __shared__ u32 ring[R::RING][R::NF][64];
+  __shared__ u32 head, produced, consumed[R::RING], broken;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (dyn) {
+    if (!tot->go) return;
+    nPoints = tot->totV;
+    nGhost = tot->V0;
+  }
+  const u64 nBatches = (nPoints + 63) >> 6;
+  const u64 NWG = gridDim.x;
+  if (blockIdx.x >= nBatches) return;
+  const u32 nb = (u32)((nBatches - blockIdx.x + NWG - 1) / NWG);      // batches of this workgroup
+  const u32 totalEntries = nb * 64u;
+  if (threadIdx.x == 0) { head = 0; produced = 0; broken = 0; for (int i = 0; i < R::RING; i++) consumed[i] = 0; }
+  __syncthreads();                                   // (the only barrier: the roles part here)
+  Sampler<T> s{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
+  const int n[3] = {g.nx, g.ny, (int)g.gnz};
+  bool unitP2I = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) unitP2I = unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
+  const int producerWave = (int)(blockIdx.x & 3);    // (rotated: which SIMD a workgroup's wave lands on is the hardware's business)
+  constexpr u32 SPIN_CAP = 1u << 24;
+  if (wv == producerWave) {
+    // ---- the producer ------------------------------------------------------------------------------------------
+    for (u32 b = 0; b < nb; b++) {
+      const u64 cand = (((u64)blockIdx.x + (u64)b * NWG) << 6) + lane;
+      const int slot = (int)(b % R::RING);
+      if (b >= (u32)R::RING) {
+        const u32 want = 64u * (b / R::RING);
+        u32 spins = 0;
+        while (__hip_atomic_load(&consumed[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
+            return;
+          }
+        }
+      }
+      float vertex[3] = {0.f, 0.f, 0.f};
+      bool valid = cand < nPoints;
+      if (valid) {
+        vertex[0] = points[3 * cand]; vertex[1] = points[3 * cand + 1]; vertex[2] = points[3 * cand + 2];
+        valid = !(cand < nGhost && vertex[0] != vertex[0]);       // (see k_project: the ghost slice's bottom plane)
+      }
+      float G[8][3];
+      SV Vd[8];
+      int kc[3] = {-2, -2, -2};
+      bool cellFinite = false;
+      if (valid) {
+        const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+        Cell8 c;
+        make_cell(geo, unitP2I, n, p, c);
+        gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
+        float tf = 0.0f;
+        double td = 0.0;
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+          td = __builtin_fma((double)Vd[counter], 0.0, td);
+#pragma unroll
+          for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
+        }
+        cellFinite = (tf == 0.0f) && (td == 0.0);
+        if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);
+#pragma unroll
+        for (int k = 0; k < 3; k++) kc[k] = c.bc[k];
+      }
+      u32 (*e)[64] = ring[slot];
+      e[0][lane] = (u32)cand;
+      e[1][lane] = __float_as_uint(vertex[0]); e[2][lane] = __float_as_uint(vertex[1]); e[3][lane] = __float_as_uint(vertex[2]);
+      e[4][lane] = (u32)kc[0]; e[5][lane] = (u32)kc[1]; e[6][lane] = (u32)kc[2];
+      e[7][lane] = (valid ? 1u : 0u) | (cellFinite ? 2u : 0u);
+      if (valid) {
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) e[8 + counter * 3 + k][lane] = __float_as_uint(G[counter][k]);
+          if constexpr (sizeof(SV) == 4) {
+            e[32 + counter][lane] = __float_as_uint((float)Vd[counter]);
+          } else {
+            const unsigned long long bits64 = (unsigned long long)__double_as_longlong((double)Vd[counter]);
+            e[32 + 2 * counter][lane] = (u32)bits64;
+            e[33 + 2 * counter][lane] = (u32)(bits64 >> 32);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the entries are in LDS
+      if (lane == 0) __hip_atomic_store(&produced, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+  // ---- a walker ----------------------------------------------------------------------------------------------------
+  const double iso = (double)iso_as<T>(prm.iso, prm.isoInt);
+  unsigned myIters = 0;
+  u32 stopStepsW = 0;
+  bool active = false, more = true;
+  u64 idx = 0;
+  float vertex[3] = {0.f, 0.f, 0.f};
+  double step = 0.0;
+  unsigned numberOfSteps = 0;
+  int kc[3] = {-2, -2, -2};
+  float G[8][3];
+  SV Vd[8];
+  bool cellFinite = false;
+  for (;;) {
+    const u64 idle = __ballot(!active);
+    if (idle && more && (__popcll(idle) >= REFILL || idle == ~0ull)) {
+      const u32 take = (u32)__popcll(idle);
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&head, take);
+      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+      if (base >= totalEntries) {
+        more = false;
+      } else {
+        const u32 endE = base + take < totalEntries ? base + take : totalEntries;
+        if (endE == totalEntries) more = false;
+        const u32 needB = (endE + 63u) >> 6;
+        u32 spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < needB) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { ok = false; break; }
+        }
+        if (!ok) {                                   // (never on a healthy launch)
+          if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
+          more = false;
+        } else if (!active) {
+          const u32 ent = base + (u32)__popcll(idle & lowmask(lane));
+          if (ent < endE) {
+            const int slot = (int)((ent >> 6) % (u32)R::RING), off = (int)(ent & 63u);
+            u32 (*e)[64] = ring[slot];
+            const u32 flags = e[7][off];
+            idx = (u64)e[0][off];
+            vertex[0] = __uint_as_float(e[1][off]); vertex[1] = __uint_as_float(e[2][off]); vertex[2] = __uint_as_float(e[3][off]);
+            kc[0] = (int)e[4][off]; kc[1] = (int)e[5][off]; kc[2] = (int)e[6][off];
+            if (flags & 1u) {
+#pragma unroll
+              for (int counter = 0; counter < 8; counter++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) G[counter][k] = __uint_as_float(e[8 + counter * 3 + k][off]);
+                if constexpr (sizeof(SV) == 4) {
+                  Vd[counter] = (SV)__uint_as_float(e[32 + counter][off]);
+                } else {
+                  const unsigned long long bits64 = (unsigned long long)e[32 + 2 * counter][off] | ((unsigned long long)e[33 + 2 * counter][off] << 32);
+                  Vd[counter] = (SV)__longlong_as_double((long long)bits64);
+                }
+              }
+              cellFinite = (flags & 2u) != 0;
+              step = prm.step;
+              numberOfSteps = 0;
+              active = true;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // the copy is in registers before the slot is given back
+            atomicAdd(&consumed[slot], 1u);
+          }
+        }
+      }
+    }
+    if (!__ballot(active)) {
+      if (!more) break;
+      continue;
+    }
+    bool bySteps = false;
+    if (active) {
+      bool done = false;
+      const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
+      Cell8 c;
+      make_cell(geo, unitP2I, n, p, c);
+      if (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2]) {
+        gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
+#pragma unroll
+        for (int k = 0; k < 3; k++) kc[k] = c.bc[k];
+        float tf = 0.0f;
+        double td = 0.0;
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+          td = __builtin_fma((double)Vd[counter], 0.0, td);
+#pragma unroll
+          for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
+        }
+        cellFinite = (tf == 0.0f) && (td == 0.0);
+        if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);
+      }
+      double o[8];
+#pragma unroll
+      for (unsigned counter = 0; counter < 8; counter++) {
+        double overlap = 1.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
+        o[counter] = overlap;
+      }
+      bool literal = !cellFinite || forceLiteral;
+      {
+        double t = o[0];
+#pragma unroll
+        for (int counter = 1; counter < 7; counter++) t += o[counter];
+        literal |= !(t < 1.0);
+      }
+      double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
+      if (!literal) {
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+          value += o[counter] * (double)Vd[counter];
+        }
+      } else {
+        double total = 0.0;
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++) {
+          if (o[counter] != 0.0 && total != 1.0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+            value += o[counter] * (double)Vd[counter];
+            total += o[counter];
+          }
+        }
+      }
+      done = fabs(value - iso) < prm.thr;                                     // txx:456
+      const unsigned passes = numberOfSteps + 1;
+      if (!done) {
+        float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
+        double sq = 0.0;                                                      // I8
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double e2 = (double)normal[k]; sq += e2 * e2; }
+        if (sq > 0.0 && sq < __builtin_inf()) {
+          // (k_project: the compiler's f64 sqrt and divisions written out for this argument range)
+          const double y0 = __builtin_amdgcn_rsq(sq);
+          double gs = sq * y0, hs = y0 * 0.5;
+          const double rs = __builtin_fma(-hs, gs, 0.5);
+          gs = __builtin_fma(gs, rs, gs);
+          hs = __builtin_fma(hs, rs, hs);
+          double ds = __builtin_fma(-gs, gs, sq);
+          gs = __builtin_fma(ds, hs, gs);
+          ds = __builtin_fma(-gs, gs, sq);
+          const double norm = __builtin_fma(ds, hs, gs);
+          double y = __builtin_amdgcn_rcp(norm);
+          double e2 = __builtin_fma(-norm, y, 1.0);
+          y = __builtin_fma(y, e2, y);
+          e2 = __builtin_fma(-norm, y, 1.0);
+          y = __builtin_fma(y, e2, y);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const double x = (double)normal[k];
+            const double q0 = x * y;
+            const double r = __builtin_fma(-norm, q0, x);
+            const double q = __builtin_fma(r, y, q0);
+            normal[k] = (float)__builtin_copysign(q, x);
+          }
+        } else {
+          const double norm = sqrt(sq);
+#pragma unroll
+          for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
+        }
+        const double sign = (value < iso) ? +1.0 : -1.0;                      // txx:463
+#pragma unroll
+        for (int k = 0; k < 3; k++)                                           // txx:464-467 (I9)
+          vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
+        step *= prm.relax;                                                    // txx:468
+        done = numberOfSteps++ > prm.max_steps;                               // txx:469
+        bySteps = done && idx >= nGhost;
+      }
+      if (done) {
+        points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
+        if (idx >= nGhost) myIters += passes;
+        active = false;
+      }
+    }
+    stopStepsW += (u32)__popcll(__ballot(bySteps));
+  }
+  unsigned sum = myIters;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
+  if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
+  if (lane == 0 && stopStepsW) atomicAdd(&tot->stopSteps, (u64)stopStepsW);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4b: the reference's two OTHER projection branches, which it compiles out (h:22-23 set both macros to 0):
 // USE_ADVANCED_PROJECTION (txx:340-397) and USE_LINESEARCH_PROJECTION (txx:398-437).  Offered for builds of the
 // reference that switch one on; never on the default path, so they are written plainly -- one lane per vertex,
@@ -3426,6 +3729,15 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     // (giving each XCD a contiguous eighth of the vertex list was measured 1.6x slower: proj_xcd stays a switch)
+    if (tn.proj_producer > 0 && mode == 0 && nPoints < 0xffffff00ull) {
+      // (the producer form: workgroups of three walking waves and one that gathers; batches of 64 per workgroup)
+      const u64 nB = (nPoints + 63) / 64;
+      const u64 wantWG = (gridWaves + 3) / 4;
+      const unsigned wgs = (unsigned)(nB < wantWG ? nB : wantWG);
+      hipLaunchKernelGGL((k_project_pw<T>), dim3(wgs), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points, nPoints,
+                         nGhost, tn.proj_refill, tn.proj_literal, w.totals, dyn);
+      return hipGetLastError();
+    }
 #define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
     hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
                        w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,  \
