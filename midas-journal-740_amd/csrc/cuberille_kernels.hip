@@ -1055,13 +1055,16 @@ __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independe
 }
 
 // The block scan as the epilogue of the LAST count block to publish its totals (k_block_scan's work for launches of at most
-// FOLD_MAX_BLOCKS blocks: all of them resident at once, so the wave that lingers for its ticket holds nobody's place; beyond
-// that a lingering block per round costs more than the 9 us launch -- round 2 measured it -- and k_block_scan stays).
+// FOLD_MAX_BLOCKS blocks -- every volume the reference ships, where an extraction's time is its number of launches: blob0 0.117
+// -> 0.109 ms, nucleon 0.174 -> 0.168, silicium 0.192 -> 0.188 wall.  Measured beyond that too, round 5: at 1024 blocks, all
+// resident at once (512^3), the ticket's return and the tail in ONE workgroup cost 4 us MORE than the second launch -- pass
+// 0.1214 against 0.1171 ms, profiles/microbench/r5_sphere512_{fold,nofold}.json -- and with several rounds of blocks a
+// lingering block per round costs more still (round 2): k_block_scan stays there).
 // Hand-off (MI355X guide, inter-workgroup visibility): every block's wave 0 stores its total (and g0pre) write-through
 // (agent-scope atomic stores = sc1), waits for them (vmcnt(0)), then adds to the ticket; the block whose add returns
 // nblk - 1 acquires at agent scope and reads every total with agent-scope loads.  The err and nVertexWords words are only ever
 // touched by device-scope atomics.
-constexpr u32 FOLD_MAX_BLOCKS = 1280;
+constexpr u32 FOLD_MAX_BLOCKS = 64;
 template <int NT>
 __device__ void block_scan_tail(const u64 *blockTot, u64 *__restrict__ blockBase, u32 nblk, size_t g0, Totals *tot, const Gate &gate,
                                 const u32 *__restrict__ sliceOcc, const Grid &g, u64 *waveSum /* NT / 64 LDS words */,
@@ -2772,69 +2775,132 @@ __global__ __launch_bounds__(256, 4) void k_project_pw(const T *__restrict__ vox
   constexpr u32 SPIN_CAP = 1u << 24;
   if (wv == producerWave) {
     // ---- the producer ------------------------------------------------------------------------------------------
-    for (u32 b = 0; b < nb; b++) {
-      const u64 cand = (((u64)blockIdx.x + (u64)b * NWG) << 6) + lane;
-      const int slot = (int)(b % R::RING);
-      if (b >= (u32)R::RING) {
-        const u32 want = 64u * (b / R::RING);
-        u32 spins = 0;
-        while (__hip_atomic_load(&consumed[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
-            return;
-          }
-        }
-      }
-      float vertex[3] = {0.f, 0.f, 0.f};
-      bool valid = cand < nPoints;
-      if (valid) {
-        vertex[0] = points[3 * cand]; vertex[1] = points[3 * cand + 1]; vertex[2] = points[3 * cand + 2];
-        valid = !(cand < nGhost && vertex[0] != vertex[0]);       // (see k_project: the ghost slice's bottom plane)
-      }
-      float G[8][3];
-      SV Vd[8];
-      int kc[3] = {-2, -2, -2};
-      bool cellFinite = false;
-      if (valid) {
-        const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
-        Cell8 c;
-        make_cell(geo, unitP2I, n, p, c);
-        gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
-        float tf = 0.0f;
-        double td = 0.0;
+    // Software-pipelined over three batches, so that a batch costs the producer its arithmetic and not two memory round
+    // trips (the first build, one batch at a time, produced 64 entries per ~4.5 us and the walkers starved: 3.1 ms against
+    // 1.19): the coordinates of batch b + 2 are on their way while the 32 pixels of batch b + 1 are, while batch b's
+    // gradients are formed and written to the ring.
+    struct Coords { float v[3]; bool valid; u64 cand; };
+    auto load_coords = [&](u32 b_, Coords &q) {
+      q.cand = (((u64)blockIdx.x + (u64)b_ * NWG) << 6) + lane;
+      q.valid = b_ < nb && q.cand < nPoints;
+      q.v[0] = q.v[1] = q.v[2] = 0.f;
+      if (q.valid) { q.v[0] = points[3 * q.cand]; q.v[1] = points[3 * q.cand + 1]; q.v[2] = points[3 * q.cand + 2]; }
+    };
+    // the 32 pixels of a unit cell (the clamped address form: the same pixels as the immediate-offset form for an interior
+    // cell); any other cell -- on or beyond the image border -- is left to gather_cell when the batch is finished
+    auto issue_gather = [&](Coords &q, Cell8 &c, T (&V)[4][4][4], bool &unit) {
+      unit = false;
+      if (q.valid) q.valid = !(q.cand < nGhost && q.v[0] != q.v[0]);       // (see k_project: the ghost slice's bottom plane)
+      if (!q.valid) return;
+      const double p[3] = {(double)q.v[0], (double)q.v[1], (double)q.v[2]};
+      make_cell(geo, unitP2I, n, p, c);
+      unit = c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2];
+      if (!unit) return;
+      int xs[4], ys[4], zs[4];
+      xs[0] = c.lo[0] > 0 ? c.lo[0] - 1 : 0;  xs[1] = c.lo[0];  xs[2] = c.hi[0];  xs[3] = c.hi[0] < s.nx - 1 ? c.hi[0] + 1 : s.nx - 1;
+      ys[0] = c.lo[1] > 0 ? c.lo[1] - 1 : 0;  ys[1] = c.lo[1];  ys[2] = c.hi[1];  ys[3] = c.hi[1] < s.ny - 1 ? c.hi[1] + 1 : s.ny - 1;
+      zs[0] = s.zlocal(c.lo[2] > 0 ? c.lo[2] - 1 : 0);  zs[1] = s.zlocal(c.lo[2]);  zs[2] = s.zlocal(c.hi[2]);
+      zs[3] = s.zlocal(c.hi[2] < s.gnz - 1 ? c.hi[2] + 1 : s.gnz - 1);
 #pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
-          td = __builtin_fma((double)Vd[counter], 0.0, td);
+      for (int zi = 0; zi < 4; zi++)
 #pragma unroll
-          for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
-        }
-        cellFinite = (tf == 0.0f) && (td == 0.0);
-        if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);
+        for (int yi = 0; yi < 4; yi++) {
+          const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2);
+          if (!zin && !yin) continue;
+          const T *row = s.vox + ((size_t)zs[zi] * s.ny + ys[yi]) * s.nx;
+          if (zin && yin) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) kc[k] = c.bc[k];
-      }
-      u32 (*e)[64] = ring[slot];
-      e[0][lane] = (u32)cand;
-      e[1][lane] = __float_as_uint(vertex[0]); e[2][lane] = __float_as_uint(vertex[1]); e[3][lane] = __float_as_uint(vertex[2]);
-      e[4][lane] = (u32)kc[0]; e[5][lane] = (u32)kc[1]; e[6][lane] = (u32)kc[2];
-      e[7][lane] = (valid ? 1u : 0u) | (cellFinite ? 2u : 0u);
-      if (valid) {
-#pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) e[8 + counter * 3 + k][lane] = __float_as_uint(G[counter][k]);
-          if constexpr (sizeof(SV) == 4) {
-            e[32 + counter][lane] = __float_as_uint((float)Vd[counter]);
+            for (int xi = 0; xi < 4; xi++) V[zi][yi][xi] = row[xs[xi]];
           } else {
-            const unsigned long long bits64 = (unsigned long long)__double_as_longlong((double)Vd[counter]);
-            e[32 + 2 * counter][lane] = (u32)bits64;
-            e[33 + 2 * counter][lane] = (u32)(bits64 >> 32);
+            V[zi][yi][1] = row[xs[1]];
+            V[zi][yi][2] = row[xs[2]];
           }
         }
+    };
+    Coords q0, q1, q2;
+    Cell8 cPrev, cNew;
+    T Vprev[4][4][4], Vnew[4][4][4];
+    bool unitPrev = false, unitNew = false;
+    load_coords(0, q1);
+    load_coords(1, q2);
+    q0 = q1;                                         // (placeholder: batch -1 does not exist)
+    q0.valid = false;
+    for (u32 b = 0; b <= nb; b++) {
+      // (1) batch b: its coordinates are here; the pixels go on their way.  (2) batch b + 2: its coordinates go on their way.
+      Coords qb = q1;
+      if (b < nb) issue_gather(qb, cNew, Vnew, unitNew);
+      q1 = q2;
+      load_coords(b + 2, q2);
+      // (3) batch b - 1: its pixels are here
+      if (b > 0) {
+        const u32 pb = b - 1;
+        const int slot = (int)(pb % R::RING);
+        float G[8][3];
+        SV Vd[8];
+        int kc[3] = {-2, -2, -2};
+        bool cellFinite = false;
+        if (q0.valid) {
+          if (unitPrev) cell_gradients<T, false>(geo, dirIdentity != 0, Vprev, G, Vd);
+          else gather_cell<T, false>(s, geo, dirIdentity != 0, cPrev, G, Vd);
+          float tf = 0.0f;
+          double td = 0.0;
+#pragma unroll
+          for (int counter = 0; counter < 8; counter++) {
+            td = __builtin_fma((double)Vd[counter], 0.0, td);
+#pragma unroll
+            for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
+          }
+          cellFinite = (tf == 0.0f) && (td == 0.0);
+          if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, cPrev, G, Vd);
+#pragma unroll
+          for (int k = 0; k < 3; k++) kc[k] = cPrev.bc[k];
+        }
+        if (pb >= (u32)R::RING) {
+          const u32 want = 64u * (pb / R::RING);
+          u32 spins = 0;
+          while (__hip_atomic_load(&consumed[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+              if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
+              return;
+            }
+          }
+        }
+        u32 (*e)[64] = ring[slot];
+        e[0][lane] = (u32)q0.cand;
+        e[1][lane] = __float_as_uint(q0.v[0]); e[2][lane] = __float_as_uint(q0.v[1]); e[3][lane] = __float_as_uint(q0.v[2]);
+        e[4][lane] = (u32)kc[0]; e[5][lane] = (u32)kc[1]; e[6][lane] = (u32)kc[2];
+        e[7][lane] = (q0.valid ? 1u : 0u) | (cellFinite ? 2u : 0u);
+        if (q0.valid) {
+#pragma unroll
+          for (int counter = 0; counter < 8; counter++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) e[8 + counter * 3 + k][lane] = __float_as_uint(G[counter][k]);
+            if constexpr (sizeof(SV) == 4) {
+              e[32 + counter][lane] = __float_as_uint((float)Vd[counter]);
+            } else {
+              const unsigned long long bits64 = (unsigned long long)__double_as_longlong((double)Vd[counter]);
+              e[32 + 2 * counter][lane] = (u32)bits64;
+              e[33 + 2 * counter][lane] = (u32)(bits64 >> 32);
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the entries are in LDS
+        if (lane == 0) __hip_atomic_store(&produced, pb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the entries are in LDS
-      if (lane == 0) __hip_atomic_store(&produced, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // roll: batch b becomes the one whose pixels are awaited
+      q0 = qb;
+      cPrev = cNew;
+      unitPrev = unitNew;
+#pragma unroll
+      for (int zi = 0; zi < 4; zi++)
+#pragma unroll
+        for (int yi = 0; yi < 4; yi++)
+#pragma unroll
+          for (int xi = 0; xi < 4; xi++) {
+            const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2), xin = (xi == 1 || xi == 2);
+            if ((zin && yin) || (zin && xin) || (yin && xin)) Vprev[zi][yi][xi] = Vnew[zi][yi][xi];
+          }
     }
     return;
   }
@@ -3539,9 +3605,6 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
     else
       hipLaunchKernelGGL((k_count<0, false, 1024>), dim3(blocks), dim3(1024), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                          w.blockTot, vq, w.totals, 0, w.blockBase, gate, 0);
-  else if (foldable)
-    hipLaunchKernelGGL((k_count<0, false, 256, true>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
-                       w.blockTot, vq, w.totals, 0, w.blockBase, gate, (int)(fold = blocks));
   else
     hipLaunchKernelGGL((k_count<0, false, 256>), dim3(blocks), dim3(256), 0, s, w.bits, w.sliceOcc, g, nwords, q1, w.prefix, w.segPre,
                        w.blockTot, vq, w.totals, 0, w.blockBase, gate, 0);
@@ -3713,12 +3776,16 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   // (round 5: where walks are SHORT -- waves that refill only when empty, a dense field -- the walk is bound by its gathers, and
   //  what those cost follows how far apart in the vertex list the waves resident at one time work: counters of the same
   //  field in rows of 512 and of 2048 voxels, profiles/r5_walk_row_width_counters.txt -- no translation misses; L1 hit rate 80 ->
-  //  68 %, L2 37 -> 24 %, 1.7x the requests beyond L2, twice the latency per request.  A wave of a 16 384-wave launch works
-  //  through 15 batches that lie 2 M vertices apart, and the 4096 resident waves are at different places of their
-  //  sequences; 65 536 waves of batches of 64 take 7: 2048 x 2048 x 256 noise 68 -> 53.5 ps per vertex, and slower again
-  //  with 131 072 (62) or one batch per wave (101: a wave's start costs more than it walks).  Long walks keep 16 384.)
+  //  68 %, L2 37 -> 24 %, 1.7x the requests beyond L2.  A wave of a 16 384-wave launch works through batches that lie
+  //  NW * chunk vertices apart, and the resident waves are at different places of their sequences: the fewer batches a wave
+  //  takes the closer together the chip works -- down to the point where a wave's start costs more than it walks.  Measured
+  //  (profiles/microbench/r5_walk_waves.log): the best launch deals batches of 64 to one wave per ~450 vertices -- 13 M
+  //  vertices (768^3 noise) 24 576-32 768 waves, 0.650 -> 0.597 ms; 31 M (1024^3) 65 536, 1.52 -> 1.37; 249 M (2048^3) 524 288,
+  //  17.0 -> 12.9 ms (18.4 in round 4) -- and loses again with half as many vertices per wave.  Long walks keep 16 384 waves.)
   const bool shortWalks = tn.proj_refill >= 64;
-  const u64 gridWaves = tn.proj_waves > 0 ? (u64)tn.proj_waves : (shortWalks ? 65536ull : 16384ull);
+  u64 autoWaves = 16384;
+  if (shortWalks && nPoints > 16384ull * 448) autoWaves = ((nPoints / 448 + 3) / 4) * 4;
+  const u64 gridWaves = tn.proj_waves > 0 ? (u64)tn.proj_waves : autoWaves;
   const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : 8000000ull;
   u64 chunk = tn.proj_chunk > 0 ? (tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk)
             : (nPoints <= 64ull * 4096 || (nPoints > 64 * gridWaves && (nPoints < upTo || shortWalks))) ? 64 : 128;

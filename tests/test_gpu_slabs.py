@@ -1,0 +1,686 @@
+"""-m gpu: Z-slabs -- slab arguments of the C ABI, the multi-rank step rehearsed with real processes on this box's one GPU
+(gloo in place of RCCL), quirk Q1 across slab boundaries, thin halo and escaped walks, the one-wait step -- against the oracle's
+mesh of the whole volume."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_same_mesh
+from conftest import point_bytes as _point_bytes
+from gpu_helpers import _bench_field, _closed_form_counts_torch, _host_threads, _read_vtk_polydata, run_gpu  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_slabs_concatenate_to_the_whole(pkg, oracle, extractor, volumes):
+    """The multi-GPU decomposition on one device: Z-slabs with halo, per-slab counts, prefix of the
+    counts as id offsets, concatenation == single-shot result == oracle."""
+    import torch
+    for name, iso, cuts in [("nucleon.mha", 128, [0, 13, 14, 30, 41]), ("fuel.mha", 15, [0, 34, 68]),
+                            ("silicium.mha", 85, [0, 7, 19, 20, 40])]:
+        vol = volumes(name)
+        nx, ny, nz = vol.dims
+        for tri in (0, 1):
+            kw = dict(triangles=tri, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+            ref = oracle.run(vol.voxels, iso, **kw)
+            prm = pkg.make_params(iso, **kw)
+            pts, cells, poff = [], [], 0
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                lo, hi = max(a - 8, 0), min(b + 8, nz)
+                slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+                desc = pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo))
+                slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
+                n_p, n_c = extractor.count(slab_vox.data_ptr(), desc, prm, slab)
+                extractor.emit(poff)
+                m = extractor.download()
+                assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
+                pts.append(m.points)
+                cells.append(m.cells)
+                poff += n_p
+            whole = pkg.Mesh(np.concatenate(pts), np.concatenate(cells))
+            assert_same_mesh(whole, ref)
+
+
+def _rank_worker(rank, world, port, name, iso, out_dir, event_path=False, step=0.24, mode="sync", relax=0.95):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import GOLDEN, ROOT
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from midas_journal_740_amd.distributed import ShardedExtractor
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vol = pkg.read_mha(os.path.join(GOLDEN, "data", name))
+        nx, ny, nz = vol.dims
+        ex = pkg.Extractor(0)
+        prm = pkg.make_params(iso, triangles=True, project=True, threshold=0.2, step=step, relax=relax, max_steps=100)
+        # mode: "sync" the host in the loop; "step" device-resident offsets (cuberille_step_begin / _end);
+        # "thin" / "step_thin": the same with the thin halo (walks that leave it are put aside and walked again)
+        # "..._bits": the bits-first halo (the neighbours' bit planes right behind the owned sweep, their voxels for the walk alone)
+        sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm,
+                              thin_halo="thin" in mode, device_offsets=mode.startswith("step"), bits_first=mode.endswith("_bits"))
+        sh.force_event_path = bool(event_path)
+        if relax == 0.95:
+            assert sh.halo == (8 if step == 0.24 else 13)
+        if "thin" in mode:
+            assert sh.thin == (3, 3)
+        buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
+        buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()   # owned slices only
+        first = sh.extract(buf, prm)
+        stats = [dict(sh.stats)]
+        if mode != "sync":
+            # a second step on the same contexts: the blind launches sized from the first one ("step"), the halo slices
+            # wiped so that the exchange has to bring them again
+            keep = (int(first.n_points), int(first.n_cells), int(first.proj_iterations))
+            buf[:sh.z0 - sh.lo].zero_()
+            buf[sh.z1 - sh.lo:].zero_()
+            second = sh.extract(buf, prm)
+            assert (int(second.n_points), int(second.n_cells), int(second.proj_iterations)) == keep
+            stats.append(dict(sh.stats))
+        if mode == "step_balanced":
+            # slabs of equal work for the next volume of the series, cut from what this step measured per slice
+            from midas_journal_740_amd.distributed import balanced_bounds
+            work = sh.slice_work(second)
+            bounds = balanced_bounds(work, world)
+            assert abs(work.sum() - work[sh.z0:sh.z1].sum()) > 0 or world == 1
+            sh = ShardedExtractor(ex, (nx, ny, nz), vol.voxels.dtype, rank, world, check_aliasing=True, params=prm,
+                                  thin_halo=True, device_offsets=True, bounds=bounds)
+            buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.uint8, device="cuda:0")
+            buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vol.voxels[sh.z0:sh.z1]).cuda()
+            sh.extract(buf, prm)
+            stats.append({"bounds": bounds})
+        np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([repr(stats)]))
+        m = ex.download()
+        np.save(os.path.join(out_dir, "p%d.npy" % rank), m.points)
+        np.save(os.path.join(out_dir, "c%d.npy" % rank), m.cells)
+        # mesh concatenation on the last rank: host buffers over gloo, or (event_path) device tensors viewed
+        # straight out of the library's buffers, the way RCCL runs move them
+        whole = sh.gather_mesh(dst=world - 1, on_device=bool(event_path))
+        assert (whole is None) == (rank != world - 1)
+        if whole is not None:
+            np.save(os.path.join(out_dir, "gp.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc.npy"), whole.cells)
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,event_path,step,mode,relax", [
+    (2, False, 0.24, "sync", 0.95), (3, False, 0.24, "step", 0.95), (2, True, 0.24, "step", 0.95), (4, False, 0.5, "sync", 0.95),
+    (3, False, 0.24, "thin", 0.95), (2, True, 0.24, "step_thin", 0.95), (4, False, 0.5, "step_thin", 0.95),
+    (3, False, 0.6, "thin", 1.0), (2, False, 0.6, "step_thin", 1.0), (4, False, 0.24, "step_balanced", 0.95),
+    (2, False, 0.24, "step_bits", 0.95), (3, True, 0.24, "step_thin_bits", 0.95), (4, False, 0.5, "step_thin_bits", 0.95),
+    (2, True, 0.6, "step_thin_bits", 1.0)])
+def test_multi_rank_rehearsal_matches_oracle(oracle, volumes, tmp_path, world, event_path, step, mode, relax):
+    """The whole N>1 path with real processes (one Extractor each, all on this box's single GPU, gloo in
+    place of RCCL): halo exchange from owned slices only, per-rank count, all-gather, emit with offsets;
+    the concatenation of the rank meshes must be the oracle's mesh of the whole volume.  event_path: the
+    non-blocking exchange + halo_ready_event branch that RCCL runs take (device tensors through gloo).  Four ranks on the
+    40 slices of silicium with a step of 0.5: 10-slice slabs under a 13-slice halo, so every rank receives from ranks
+    beyond its neighbours (four ranks, not more: the box allows six processes on its GPU, this one included).
+    mode "step": the step without a host round trip between count and emit, twice on the same contexts (sized by a host
+    read, then blind).  "thin": only 3 + 3 halo slices cross per step; with step 0.6 and no relaxation (102 steps of 0.6:
+    walks cross whole slabs) many walks leave them, every rank fetches the rest of the halo and walks those again."""
+    import socket
+    import torch.multiprocessing as mp
+    name, iso = "silicium.mha", 85
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_worker, args=(world, port, name, iso, str(tmp_path), event_path, step, mode, relax), nprocs=world, join=True)
+    pts = np.concatenate([np.load(str(tmp_path / ("p%d.npy" % r))) for r in range(world)])
+    cells = np.concatenate([np.load(str(tmp_path / ("c%d.npy" % r))) for r in range(world)])
+    ref = oracle.run(volumes(name).voxels, iso, triangles=True, project=True, threshold=0.2, step=step, relax=relax,
+                     max_steps=100)
+    stats = [eval(str(np.load(str(tmp_path / ("stats%d.npy" % r)))[0])) for r in range(world)]
+    if "thin" in mode:
+        # 3 + 3 slices instead of the full halo -- unless walks left them (relax 1.0: they do)
+        assert all(st[0]["deep_halo_fetched"] == (relax == 1.0) for st in stats), stats
+        if relax == 1.0:
+            assert sum(st[0]["escaped"] for st in stats) > 0
+    if mode == "step_balanced":
+        # every rank derives the same cuts from the all-reduced per-slice work (measured times: where they fall is the
+        # box's business -- tests/test_distributed.py pins balanced_bounds itself), and they tile the 40 slices
+        bounds = stats[0][-1]["bounds"]
+        assert all(st[-1]["bounds"] == bounds for st in stats)
+        assert bounds[0][0] == 0 and bounds[-1][1] == 40 and all(b > a for a, b in bounds)
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    elif mode.startswith("step"):
+        # (one collective per step; where walks escape: the row all-gather, the count all-gather of the synchronous protocol
+        #  that takes over, and its closing gather)
+        assert all(st[-1]["collectives"] == (1 if relax == 0.95 else 3) for st in stats), stats
+        if mode.endswith("_bits"):
+            # a bit plane per halo slice: 1/8 of the uint8 voxels' bytes here (1/32 for float32), rounded up to words per row
+            wps = 40 * ((104 + 63) // 64)
+            assert all(st[-1]["halo_bit_bytes"] * (104 * 40) == st[-1]["halo_bytes"] * wps * 8 for st in stats
+                       if st[-1]["halo_bytes"] and not st[-1]["deep_halo_fetched"]), stats
+            assert all(st[-1]["halo_bit_bytes"] > 0 for st in stats), stats
+
+    class M:
+        pass
+    m = M()
+    m.points, m.cells = pts, cells
+    assert_same_mesh(m, ref)
+    m.points, m.cells = np.load(str(tmp_path / "gp.npy")), np.load(str(tmp_path / "gc.npy"))   # gather_mesh on rank world-1
+    assert_same_mesh(m, ref)
+
+
+def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, volumes):
+    """cuberille_slab.halo_ready_event: the halo slices of the buffer are still being written (here by a
+    copy on a side stream, in production by the RCCL exchange) when cuberille_count is called; the library
+    thresholds the owned slices first and the halo slices only after the event."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    prm = pkg.make_params(85, **kw)
+    full = torch.from_numpy(vol.voxels).cuda()
+    side = torch.cuda.Stream()
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 14), (14, 29), (29, 40)]:
+        lo, hi = max(a - 8, 0), min(b + 8, nz)
+        buf = torch.full((hi - lo, ny, nx), 255, dtype=torch.uint8, device="cuda")     # wrong halo content
+        buf[a - lo:b - lo] = full[a:b]
+        torch.cuda.synchronize()
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(20_000_000)                                                # the "exchange" takes a while
+            buf[:a - lo] = full[lo:a]
+            buf[b - lo:] = full[b:hi]
+            ev.record(side)
+        desc = pkg.make_desc(np.uint8, (nx, ny, hi - lo))
+        slab = pkg._abi.Slab(nz, lo, a, b, 0, 0, ev.cuda_event)
+        n_p, n_c = extractor.count(buf.data_ptr(), desc, prm, slab)
+        extractor.emit(poff)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def test_rccl_and_library_share_one_process(tmp_path):
+    """One rank, backend nccl (= RCCL): process-group init, all-gather of the counts on device tensors, all-reduce
+    and barrier next to libcuberille_hip.so in the same process (both must bind the HIP runtime torch ships); and the
+    one-wait step (cuberille_step_begin -> RCCL all_gather_into_tensor of the rows in device memory -> cuberille_step_end)
+    with that world of one.  The N>1 exchange itself needs more than one GPU; the gloo rehearsals above cover its logic."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(_RCCL_SMOKE)
+    env = dict(os.environ, CUBERILLE_ROOT=ROOT, CUBERILLE_PORT=str(port))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_SMOKE_OK" in r.stdout, (r.stdout[-600:], r.stderr[-1500:])
+
+
+def test_slab_halo_is_sized_by_the_parameters(pkg, oracle, extractor):
+    """A slab must hold what the projection can reach: thin z spacing and a longer step need more than the 8 slices
+    of the defaults.  The library says how many (cuberille_required_halo), refuses less (CUBERILLE_ERR_HALO instead
+    of silently clamping the walk at the buffer edge), and with that halo the slabs reproduce the one-shot mesh."""
+    import torch
+    vox = pkg.volumes.sphere_sdf(72)
+    spacing = (1.0, 1.0, 0.25)
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.4, relax=0.97, max_steps=60)
+    prm = pkg.make_params(0.0, **kw)
+    ref = oracle.run(vox, 0.0, spacing=spacing, **kw)
+    nz, n = vox.shape[0], vox.shape[2]
+    halo = max(pkg.required_halo(pkg.make_desc(np.float32, (n, n, nz), spacing), prm))
+    assert halo > 30
+    dev = torch.from_numpy(vox).cuda()
+    a, b = 0, 36
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        hi = b + 8
+        extractor.count(dev[:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi), spacing), prm, pkg._abi.Slab(nz, 0, a, b, 0, 0))
+    assert e.value.code == pkg._abi.ERR_HALO and "cuberille_required_halo" in str(e.value)
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 36), (36, 72)]:
+        lo, hi = max(a - halo, 0), min(b + halo, nz)
+        slab = pkg._abi.Slab(nz, lo, a, b, 0, 0)
+        n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (n, n, hi - lo), spacing), prm, slab)
+        extractor.emit(poff)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def _q1_worker(rank, world, port, vol_path, iso, kw, out_dir, options=()):
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    from midas_journal_740_amd.distributed import ShardedExtractor
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vox = np.load(vol_path)
+        nz, ny, nx = vox.shape
+        prm = pkg.make_params(iso, **kw)
+        ex = pkg.Extractor(0)
+        thin = "thin_halo" in options
+        for o in options:
+            name, _, value = o.partition("=")
+            if name != "thin_halo":
+                ex.debug_option(name, int(value or 1))
+        sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, params=prm, thin_halo=thin)
+        buf = torch.zeros((sh.hi - sh.lo, ny, nx), dtype=torch.from_numpy(vox[:1]).dtype, device="cuda:0")
+        buf[sh.z0 - sh.lo:sh.z1 - sh.lo] = torch.from_numpy(vox[sh.z0:sh.z1]).cuda()      # owned slices only
+        first = sh.extract(buf, prm)
+        whole = sh.gather_mesh(dst=0, on_device=False)
+        if whole is not None:
+            np.save(os.path.join(out_dir, "gp.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc.npy"), whole.cells)
+        # two more steps on the same contexts: launched blindly from the sizes of the one before (the halo slices wiped, so
+        # that the exchange has to bring them again) -- the same mesh, and what the step cost besides kernels
+        stats = [dict(sh.stats)]
+        for _ in range(2):
+            buf[:sh.z0 - sh.lo].zero_()
+            buf[sh.z1 - sh.lo:].zero_()
+            again = sh.extract(buf, prm)
+            assert (int(again.n_points), int(again.n_cells)) == (int(first.n_points), int(first.n_cells))
+            stats.append(dict(sh.stats))
+        whole = sh.gather_mesh(dst=0, on_device=False)
+        if whole is not None:
+            np.save(os.path.join(out_dir, "gp2.npy"), whole.points)
+            np.save(os.path.join(out_dir, "gc2.npy"), whole.cells)
+        np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([repr(stats)]))
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["two_voxels_empty_rank_between", "source_in_the_halo", "source_in_the_halo_no_corner_map",
+                                  "marschner_lobb_stacked", "ghost_lowest_occupied", "ghost_source_in_the_halo",
+                                  "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source", "nothing_occupied_below",
+                                  "source_in_the_halo_dense_count", "source_in_the_halo_ragged_dense_count",
+                                  "ghost_source_below_the_buffer_dense_count", "nothing_occupied_below_thin_halo_escaping_walks"])
+def test_empty_slice_aliasing_across_slab_boundaries(pkg, oracle, tmp_path, case):
+    """Quirk Q1 (txx:139-141 before 156-161) when the run of empty slices contains a slab boundary: the rank above
+    re-uses vertices the rank below created.  Real processes over gloo on this box's GPU: the source slice's inside
+    bits travel up before the (re)count, the ids and final positions of its top-plane vertices before the cells are
+    written; the gathered mesh equals the oracle's mesh of the whole volume -- ids, order, float bits."""
+    import socket
+    import torch.multiprocessing as mp
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.25, relax=0.95, max_steps=50)
+    if case == "two_voxels_empty_rank_between":
+        vox = np.zeros((48, 8, 8), dtype=np.uint8)          # 3 ranks of 16 slices; the middle one holds nothing
+        vox[10, 3, 3] = 255
+        vox[10, 4, 3] = 255
+        vox[40, 3, 3] = 255
+        iso, world = 128, 3
+    elif case == "nothing_occupied_below_thin_halo_escaping_walks":
+        # (round-4 advisor finding) a THIN halo, rank 1's buffer starts in empty space (slices 29..32; its first occupied
+        # slice 33 raises the "source below my buffer?" flag, nobody below holds one) AND its walks -- long steps, no
+        # relaxation -- leave the thin halo: the flag no longer closes the gate, so the blind walk runs and escapes; the
+        # escapes must still reach every rank (a second small gather), the deep halo must be fetched and the walks redone
+        rng = np.random.default_rng(17)
+        vox = np.zeros((64, 12, 70), dtype=np.uint8)
+        vox[33:45] = (rng.random((12, 12, 70)) < 0.3) * 255
+        iso, world = 128, 2
+        kw.update(step=0.6, relax=1.0)
+    elif case == "nothing_occupied_below":
+        # rank 1's first occupied slice (40) has only empty slices below it in its buffer (from 24 on) and rank 0 holds
+        # nothing at all: the count raises its "source below my buffer?" flag, the rows of the ranks below answer it on the
+        # device -- no rank owns an occupied slice -- and the step stays a one-wait step (round-3 advisor finding: every
+        # such step used to come back with CUBERILLE_RETRY and take the synchronous protocol on top)
+        rng = np.random.default_rng(5)
+        vox = np.zeros((64, 12, 70), dtype=np.uint8)
+        vox[40:50] = (rng.random((10, 12, 70)) < 0.3) * 255
+        iso, world = 128, 2
+    elif case.startswith("source_in_the_halo"):
+        # (..._dense_count: rows of whole words, so that the dense form of the count -- k_count_dense, forced -- meets the
+        #  aliased source slice, in the buffer here, handed over by the rank below in the ghost case further down)
+        nx_ = 128 if case.endswith("dense_count") and "ragged" not in case else 70
+        rng = np.random.default_rng(3)
+        vox = np.zeros((40, 12, nx_), dtype=np.uint8)       # cut at 20; slices 16..21 empty, source slice 15 in the halo
+        vox[8:16] = (rng.random((8, 12, nx_)) < 0.3) * 255
+        vox[22:30] = (rng.random((8, 12, nx_)) < 0.3) * 255
+        iso, world = 128, 2
+    elif case.startswith("ghost"):
+        # the aliased slice is a rank's GHOST slice (the last slice of the rank below): round-2 advisor finding, the
+        # plan then took the ghost slice itself for the source and the cells of the first owned slice came out wrong
+        rng = np.random.default_rng(11)
+        nx_ = 64 if case.endswith("dense_count") else 70
+        fill = lambda a, b: (rng.random((b - a, 12, nx_)) < 0.3) * 255
+        if case == "ghost_lowest_occupied":                 # cut at 20; slice 19 is the lowest occupied slice of the volume
+            vox = np.zeros((40, 12, 70), dtype=np.uint8)
+            vox[19:28] = fill(19, 28)
+            iso, world = 128, 2
+        elif case == "ghost_source_in_the_halo":            # 14..15 occupied, 16..18 empty, 19.. occupied; buffer from 12
+            vox = np.zeros((40, 12, 70), dtype=np.uint8)
+            vox[14:16] = fill(14, 16)
+            vox[19:28] = fill(19, 28)
+            iso, world = 128, 2
+        elif case.startswith("ghost_source_below_the_buffer"):       # cut at 32, buffer from 24; 10..12, then 31.. occupied
+            vox = np.zeros((64, 12, nx_), dtype=np.uint8)
+            vox[10:13] = fill(10, 13)
+            vox[31:40] = fill(31, 40)
+            iso, world = 128, 2
+        else:                                               # 3 ranks of 16; slice 3, then 31..: rank 1 (owned slice 31) and
+            vox = np.zeros((48, 12, 70), dtype=np.uint8)    # rank 2 (ghost slice 31) both go back to rank 0's slice 3
+            vox[3:4] = fill(3, 4)
+            vox[31:40] = fill(31, 40)
+            iso, world = 128, 3
+    else:
+        vox = pkg.volumes.marschner_lobb(64, 0, 128, period=64)   # the weak-scaling volume of bench.py in small
+        iso, world = 0.5, 2
+        kw["threshold"] = 0.002
+    ref = oracle.run(vox, iso, **kw)
+    closed_pts, _ = oracle.closed_form_counts(vox, iso)
+    assert (len(ref.points) < closed_pts) == (case not in ("ghost_lowest_occupied", "nothing_occupied_below",
+                                                           "nothing_occupied_below_thin_halo_escaping_walks"))    # the reference really re-uses vertices
+    np.save(str(tmp_path / "vol.npy"), vox)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    options = ("no_cmap", "no_heads") if case.endswith("no_corner_map") else ("count_variant=34",) if case.endswith("dense_count") else \
+        ("thin_halo",) if "thin_halo" in case else ()
+    mp.spawn(_q1_worker, args=(world, port, str(tmp_path / "vol.npy"), iso, kw, str(tmp_path), options), nprocs=world, join=True)
+
+    class M:
+        pass
+    m = M()
+    m.points, m.cells = np.load(str(tmp_path / "gp.npy")), np.load(str(tmp_path / "gc.npy"))
+    assert_same_mesh(m, ref)
+    m.points, m.cells = np.load(str(tmp_path / "gp2.npy")), np.load(str(tmp_path / "gc2.npy"))     # after the blind steps
+    assert_same_mesh(m, ref)
+    stats = [eval(str(np.load(str(tmp_path / ("stats%d.npy" % r)))[0])) for r in range(world)]
+    if "escaping_walks" in case:
+        # the walks really left the thin halo, on rank 1, in every step; the deep halo came each time
+        assert all(st["escaped"] > 0 and st["deep_halo_fetched"] for st in stats[1]), stats
+        assert all(st["deep_halo_fetched"] for st in stats[0]), stats
+    elif case == "nothing_occupied_below":
+        # every step one collective (the row all-gather), the blind ones with the rehearsal's two host waits (gloo stages
+        # the rows through the host; RCCL: one)
+        assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank), stats
+        assert all(st["host_syncs"] <= 3 for per_rank in stats for st in per_rank[1:]), stats
+    elif case == "ghost_lowest_occupied":
+        # the aliased slice is the lowest occupied slice of the volume: no source, nothing to hand over -- decided from the
+        # rows on the device since the second-highest occupied slices ride in them
+        assert all(st["collectives"] == 1 for per_rank in stats for st in per_rank[1:]), stats
+    elif case in ("two_voxels_empty_rank_between", "ghost_source_below_the_buffer", "ghost_and_owned_share_a_source",
+                  "ghost_source_below_the_buffer_dense_count"):
+        # a real hand-over: the synchronous protocol with its gathers, every step
+        assert all(st["collectives"] >= 2 for per_rank in stats for st in per_rank), stats
+
+
+# ---- the reference's two compiled-out projection branches (h:22-23; txx:340-397, 398-437) -----------------------------
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_compiled_out_projection_branches_in_slabs(pkg, oracle, extractor, volumes, variant):
+    """Both branches travel no farther than the shipped walk, so cuberille_required_halo covers them: slabs with
+    exactly that halo concatenate to the oracle's whole-volume mesh."""
+    import torch
+    vol = volumes("fuel.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=30)
+    want = oracle.run(vol.voxels, 15, variant=variant, **kw)
+    prm = pkg.make_params(15, variant=variant, **kw)
+    below, above = pkg.required_halo(pkg.make_desc(vol.voxels.dtype, vol.dims), prm)
+    pts, cells, poff, iters = [], [], 0, 0
+    for a, b in zip([0, 21, 22, 40], [21, 22, 40, nz]):
+        lo, hi = max(a - below, 0), min(b + above, nz)
+        slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+        n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo)), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        res = extractor.emit(poff)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+        iters += int(extractor.result.proj_iterations)
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), want)
+    assert iters == want.info["proj_iterations"]
+
+
+def test_slabs_without_the_aliasing_quirk(pkg, extractor):
+    """emulate_empty_slice_aliasing = 0 in slab mode: no slice of another rank is ever needed beyond the halo, and the
+    slabs of a sparse volume with empty slices AT the cuts concatenate to the one-shot mesh of the same setting."""
+    import torch
+    rng = np.random.default_rng(123)
+    vox = (rng.random((40, 9, 70)) < 0.05).astype(np.uint8) * 255
+    vox[9:12] = 0
+    vox[19:21] = 0
+    vox[30] = 0
+    vol = pkg.Volume(vox)
+    nx, ny, nz = vol.dims
+    for tri in (False, True):
+        kw = dict(triangles=tri, project=True, threshold=0.5, step=0.25, relax=0.95, max_steps=20, q1=False)
+        prm = pkg.make_params(128, **kw)
+        extractor.extract_host(vol, prm)
+        whole = extractor.download()
+        below, above = pkg.required_halo(pkg.make_desc(vox.dtype, vol.dims), prm)
+        pts, cells, poff = [], [], 0
+        for a, b in zip([0, 10, 20, 31], [10, 20, 31, nz]):
+            lo, hi = max(a - below, 0), min(b + above, nz)
+            slab_vox = torch.from_numpy(np.ascontiguousarray(vox[lo:hi])).cuda()
+            n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vox.dtype, (nx, ny, hi - lo)), prm,
+                                       pkg._abi.Slab(nz, lo, a, b, 0, 0))
+            soft = extractor.slab_info().alias_below
+            assert not soft                                   # nothing to resolve with the quirk off
+            extractor.emit(poff)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+        got = pkg.Mesh(np.concatenate(pts), np.concatenate(cells))
+        assert np.array_equal(got.cells, whole.cells)
+        assert _point_bytes(got.points) == _point_bytes(whole.points)
+
+
+def test_slabs_under_a_tilted_direction_matrix(pkg, oracle, extractor):
+    """The halo follows the z row of PhysicalPointToIndex: with the image tilted about its x axis (physical steps mix
+    into index y and z) and anisotropic spacing, slabs carrying exactly cuberille_required_halo reproduce the oracle's
+    whole-volume mesh, coordinates bit for bit."""
+    import torch
+    vox = pkg.volumes.sphere_sdf(56)
+    th = 0.4
+    direction = np.array([[1.0, 0.0, 0.0], [0.0, np.cos(th), -np.sin(th)], [0.0, np.sin(th), np.cos(th)]])
+    geo = dict(spacing=(1.0, 0.8, 0.6), origin=(2.0, -3.0, 0.5), direction=direction)
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.3, relax=0.95, max_steps=40)
+    prm = pkg.make_params(0.0, **kw)
+    ref = oracle.run(vox, 0.0, **geo, **kw)
+    nz, ny, nx = vox.shape
+    below, above = pkg.required_halo(pkg.make_desc(np.float32, (nx, ny, nz), **geo), prm)
+    assert below > 8                      # more than the unit-spacing default
+    dev = torch.from_numpy(vox).cuda()
+    pts, cells, poff = [], [], 0
+    for a, b in [(0, 17), (17, 30), (30, 56)]:
+        lo, hi = max(a - below, 0), min(b + above, nz)
+        n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (nx, ny, hi - lo), **geo), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        extractor.emit(poff)
+        m = extractor.download()
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
+    """cuberille_emit_points between count and emit (the multi-GPU driver calls it before the count all-gather): the
+    vertices are scattered and projected without the id offsets, cuberille_emit adds the cells -- same mesh as without
+    it; calling it with nothing counted is a state error; a recount after it starts over."""
+    import torch
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        pkg.Extractor(0).emit_points()
+    assert e.value.code == pkg._abi.ERR_STATE
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    prm = pkg.make_params(85, **kw)
+    pts, cells, poff = [], [], 0
+    for a, b in zip([0, 11, 25], [11, 25, nz]):
+        lo, hi = max(a - 8, 0), min(b + 8, nz)
+        slab_vox = torch.from_numpy(np.ascontiguousarray(vol.voxels[lo:hi])).cuda()
+        n_p, n_c = extractor.count(slab_vox.data_ptr(), pkg.make_desc(vol.voxels.dtype, (nx, ny, hi - lo)), prm,
+                                   pkg._abi.Slab(nz, lo, a, b, 0, 0))
+        extractor.emit_points()
+        extractor.emit_points()                              # harmless twice
+        torch.cuda.synchronize()
+        extractor.emit(poff)
+        m = extractor.download()
+        assert m.points.shape[0] == n_p and m.cells.shape[0] == n_c
+        pts.append(m.points)
+        cells.append(m.cells)
+        poff += n_p
+    assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+
+
+# ---- round 3: every instantiation of the large-volume sweep, 64-bit pixels, counters, thin halo, one-wait step -----------
+
+
+def test_thin_halo_slabs_equal_the_one_shot_mesh(pkg, oracle, extractor, volumes):
+    """CUBERILLE_SLAB_THIN_HALO in one process: slabs that hold 3 + 3 halo slices (cuberille_minimum_halo + 1) instead
+    of the 8 the walk can reach give the oracle's mesh bit for bit -- with no walk leaving them at the driver's
+    parameters, and, when walks are forced out (step 0.6, no relaxation), through the escape list and
+    cuberille_reproject_escaped on the full buffer; cuberille_emit refuses while walks wait."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    desc_all = pkg.make_desc(np.uint8, (nx, ny, nz))
+    for step, relax, expect_escapes in [(0.24, 0.95, False), (0.6, 1.0, True)]:
+        kw = dict(triangles=1, project=1, threshold=0.2, step=step, relax=relax, max_steps=100)
+        prm = pkg.make_params(85, **kw)
+        ref = oracle.run(vol.voxels, 85, **kw)
+        assert pkg.cuberille.minimum_halo(desc_all, prm) == (2, 2)
+        assert pkg.cuberille.minimum_halo(desc_all, pkg.make_params(85, project=False)) == (2, 1)
+        deep = max(pkg.cuberille.required_halo(desc_all, prm))
+        pts, cells, poff, escaped, iters = [], [], 0, 0, 0
+        for a, b in [(0, 9), (9, 10), (10, 27), (27, nz)]:
+            lo, hi = max(a - 3, 0), min(b + 3, nz)
+            slab = pkg._abi.Slab(nz, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO)
+            n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, hi - lo)), prm, slab)
+            extractor.emit_points()
+            n_esc = extractor.escaped_count()
+            escaped += n_esc
+            if n_esc:
+                with pytest.raises(pkg._abi.CuberilleError) as e:
+                    extractor.emit(poff)
+                assert e.value.code == pkg._abi.ERR_HALO
+                with pytest.raises(pkg._abi.CuberilleError) as e:      # a buffer that is still too thin is refused
+                    extractor.reproject_escaped(dev[lo:hi].data_ptr(), lo, hi - lo)
+                assert e.value.code == pkg._abi.ERR_HALO
+                dlo, dhi = max(a - deep, 0), min(b + deep, nz)
+                extractor.reproject_escaped(dev[dlo:dhi].data_ptr(), dlo, dhi - dlo)
+            r = extractor.emit(poff)
+            assert int(r.n_escaped) == 0
+            iters += int(r.proj_iterations)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+
+        class M:
+            pass
+        m = M()
+        m.points, m.cells = np.concatenate(pts), np.concatenate(cells)
+        assert_same_mesh(m, ref)
+        assert iters == ref.info["proj_iterations"]
+        assert (escaped > 0) == expect_escapes, escaped
+    # a thin slab must still hold the topology's slices, and is not offered with the compiled-out projection branches
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.count(dev[9:21].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, 12)), prm, pkg._abi.Slab(nz, 9, 10, 20, 0, pkg._abi.SLAB_THIN_HALO))
+    assert e.value.code == pkg._abi.ERR_HALO
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.count(dev[7:23].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, 16)), pkg.make_params(85, variant=1, **kw),
+                        pkg._abi.Slab(nz, 7, 10, 20, 0, pkg._abi.SLAB_THIN_HALO))
+    assert e.value.code == pkg._abi.ERR_ARGUMENT
+
+
+def test_one_wait_step_on_one_rank(pkg, oracle, volumes):
+    """cuberille_step_begin / cuberille_step_end with a single rank (the row is its own gather): the first extraction on
+    a context sizes its launches by a host read, the following ones blindly from the one before; a volume whose counts
+    exceed that guess comes back with CUBERILLE_RETRY, the synchronous calls finish it, and the next step is blind again."""
+    import torch
+    ex = pkg.Extractor(0)
+    try:
+        kw = dict(triangles=1, project=1, threshold=0.2, step=0.24, relax=0.95, max_steps=100)
+        refs = {}
+        for round_ in range(2):
+            for name, iso in [("fuel.mha", 15), ("fuel.mha", 15), ("blob0.mha", 200), ("hydrogenAtom.mha", 15), ("nucleon.mha", 140)]:
+                vol = volumes(name)
+                nx, ny, nz = vol.dims
+                dev = torch.from_numpy(vol.voxels).cuda()
+                torch.cuda.synchronize()
+                desc, prm = pkg.make_desc(np.uint8, (nx, ny, nz)), pkg.make_params(iso, **kw)
+                if name not in refs:
+                    refs[name] = oracle.run(vol.voxels, iso, **kw)
+                ref = refs[name]
+                ptr, nbytes = ex.step_begin(dev.data_ptr(), desc, prm)
+                assert nbytes % 8 == 0
+                res, done = ex.step_end(ptr, 1, 0)
+                assert (int(res.n_points), int(res.n_cells)) == (len(ref.points), len(ref.cells))
+                if not done:
+                    # hydrogenAtom after blob0 (8 points): far beyond the guess
+                    assert name == "hydrogenAtom.mha"
+                    res = ex.emit(0)
+                assert_same_mesh(ex.download(), ref)
+                assert int(res.proj_iterations) == ref.info["proj_iterations"]
+                assert int(res.proj_stop_steps) == ref.info["proj_stop_steps"]
+                del dev
+    finally:
+        ex.close()
+
+
+def test_slice_counts_add_up(pkg, oracle, extractor, volumes):
+    """cuberille_slice_counts: vertices created and quads emitted per owned slice of the last count -- they add up to the
+    totals, equal what the oracle's mesh says slice by slice (a vertex belongs to the slice of the voxel that created it:
+    ids are handed out in raster order, so the per-slice counts are the gaps between the first ids of the slices), on the
+    whole volume and on a slab."""
+    import torch
+    vol = volumes("silicium.mha")
+    nx, ny, nz = vol.dims
+    kw = dict(triangles=0, project=0)
+    ref = oracle.run(vol.voxels, 85, **kw)
+    res = extractor.extract_host(vol, pkg.make_params(85, **kw))
+    pts, quads = extractor.slice_counts(nz)
+    assert int(pts.sum()) == int(res.n_points) == len(ref.points) and int(quads.sum()) == int(res.n_cells) == len(ref.cells)
+    # quads per slice from the oracle's cells: a quad's slice is its voxel's z = floor of the smallest corner z + 1/2 ... its
+    # unprojected corners sit at lattice z - 1/2, and the cell order is voxel raster order: count them by the closed form
+    ins = vol.voxels >= 85
+    want_q = np.zeros(nz, dtype=np.int64)
+    for ax in range(3):
+        a = np.moveaxis(ins, ax, 0)
+        up = np.moveaxis(a[:-1] & ~a[1:], 0, ax)            # face towards +axis of the lower voxel
+        dn = np.moveaxis(a[1:] & ~a[:-1], 0, ax)            # face towards -axis of the upper voxel
+        if ax == 0:
+            want_q[:-1] += up.reshape(nz - 1, -1).sum(1)
+            want_q[1:] += dn.reshape(nz - 1, -1).sum(1)
+        else:
+            want_q += up.reshape(nz, -1).sum(1) + dn.reshape(nz, -1).sum(1)
+    assert np.array_equal(quads.astype(np.int64), want_q)
+    dev = torch.from_numpy(vol.voxels).cuda()
+    torch.cuda.synchronize()
+    a, b = 11, 29
+    lo, hi = a - 3, b + 3
+    extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.uint8, (nx, ny, hi - lo)), pkg.make_params(85, **kw), pkg._abi.Slab(nz, lo, a, b, 0, 0))
+    p2, q2 = extractor.slice_counts(b - a)
+    assert np.array_equal(q2, quads[a:b]) and np.array_equal(p2, pts[a:b])
+    extractor.emit(0)
+    with pytest.raises(pkg._abi.CuberilleError):
+        extractor.slice_counts(b - a + 1)
