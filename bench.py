@@ -64,8 +64,13 @@ WORKLOADS = {
 
 
 # the rocprofv3 PMC summary (profiles/collect.sh) of exactly the configuration a line reports: workload, edge -> file
-PMC_FILES = {("marschner_lobb", 1024): "r4_pmc_hbm.csv", ("sphere", 512): "r4_config3_sphere512_pmc_hbm.csv"}
-PASS_KERNELS = ("k_classify_span<float", "k_classify_flat<float", "k_count<", "k_block_scan")
+# (file, scale, note): configs[4]'s counters are taken on a 2048 x 2048 x 256 slab of the same field -- rocprofv3's counter passes
+# die on the 8.6 GB volume -- and scaled by the slice ratio: every pass kernel's traffic is proportional to the slices it sweeps
+PMC_FILES = {("marschner_lobb", 1024): ("r4_pmc_hbm.csv", 1.0, None), ("sphere", 512): ("r4_config3_sphere512_pmc_hbm.csv", 1.0, None),
+             ("noise", 2048): ("r5_config5_slab2048x2048x256_pmc_hbm.csv", 8.0,
+                               "counted on a 2048 x 2048 x 256 slab of the same field (the counter passes do not survive the "
+                               "8.6 GB volume), scaled by 2048 / 256")}
+PASS_KERNELS = ("k_classify_span<", "k_classify_flat<", "k_classify_span_rows<", "k_count<", "k_count_dense", "k_block_scan", "k_block_partial")
 
 
 def measured_traffic(args, world, alg_bytes):
@@ -74,10 +79,11 @@ def measured_traffic(args, world, alg_bytes):
     the bytes of a 16 B/lane coalesced stream, so the sweep's is doubled -- MI355X_MICROARCH.md, HBM section; the
     count kernel's 8-byte accesses are uncalibrated and taken as counted).  Only valid for the configuration the
     profile was taken on; otherwise null."""
-    name = PMC_FILES.get((args.workload, args.size))
-    if world != 1 or name is None or args.no_project or args.thr is not None:
+    entry = PMC_FILES.get((args.workload, args.size))
+    if world != 1 or entry is None or args.no_project or args.thr is not None:
         return None, None
     import csv
+    name, scale, note = entry
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
@@ -93,9 +99,9 @@ def measured_traffic(args, world, alg_bytes):
         elif row["counter"] == "WRITE_SIZE":
             total += kb
             seen.add((k, "W"))
-    if not any(k.startswith("k_classify") for k, _ in seen) or ("k_count<", "F") not in seen:
+    if not any(k.startswith("k_classify") for k, _ in seen) or not any(k.startswith("k_count") and f == "F" for k, f in seen):
         return None, None
-    return total * 1024.0, os.path.relpath(path, ROOT)
+    return total * 1024.0 * scale, os.path.relpath(path, ROOT) + ("" if note is None else " -- " + note)
 
 
 def slab_probe(pkg, torch, ex, buf, n, dtype, prm, reps=20):

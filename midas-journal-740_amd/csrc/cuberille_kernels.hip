@@ -3782,9 +3782,15 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   //  (profiles/microbench/r5_walk_waves.log): the best launch deals batches of 64 to one wave per ~450 vertices -- 13 M
   //  vertices (768^3 noise) 24 576-32 768 waves, 0.650 -> 0.597 ms; 31 M (1024^3) 65 536, 1.52 -> 1.37; 249 M (2048^3) 524 288,
   //  17.0 -> 12.9 ms (18.4 in round 4) -- and loses again with half as many vertices per wave.  Long walks keep 16 384 waves.)
+  //  LONG walks (the refilling waves, Marschner-Lobb): the same sweeps give one wave per ~680 vertices -- which IS the 16 384 waves
+  //  of rounds 1-4 at the headline's 11.1 M vertices (12 288 / 16 384 / 20 480 / 24 576 waves: 1.157 / 1.144 / 1.193 / 1.170 ms) --
+  //  512^3 (2.8 M vertices) 4096 waves 0.388 against 0.439 ms, 768^3 12 288 waves 0.717 against 0.739, 2048^3 (44.8 M)
+  //  65 536 waves 4.14 against 4.30.  Below 4096 waves' worth of vertices the launch shapes of rounds 3-4 stand.)
   const bool shortWalks = tn.proj_refill >= 64;
+  const u64 perWave = shortWalks ? 448 : 680;
   u64 autoWaves = 16384;
-  if (shortWalks && nPoints > 16384ull * 448) autoWaves = ((nPoints / 448 + 3) / 4) * 4;
+  if (shortWalks ? nPoints > 16384ull * perWave : nPoints >= 4096ull * perWave) autoWaves = ((nPoints / perWave + 3) / 4) * 4;
+  if (autoWaves < 4096) autoWaves = 4096;
   const u64 gridWaves = tn.proj_waves > 0 ? (u64)tn.proj_waves : autoWaves;
   const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : 8000000ull;
   u64 chunk = tn.proj_chunk > 0 ? (tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk)

@@ -209,6 +209,57 @@ def test_halo_ready_event_orders_halo_classification(pkg, oracle, extractor, vol
     assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
 
 
+_RCCL_SMOKE = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["CUBERILLE_ROOT"])
+import __graft_entry__ as graft
+pkg = graft.load_package()
+from midas_journal_740_amd.distributed import ShardedExtractor, gather_counts, exchange_halos
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", os.environ["CUBERILLE_PORT"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+try:
+    n = 96
+    vol = pkg.volumes.sphere_sdf(n, xp=torch, device=dev)
+    ex = pkg.Extractor(0)
+    sh = ShardedExtractor(ex, (n, n, n), np.float32, 0, 1)
+    prm = pkg.make_params(0.0, triangles=True, project=True, threshold=0.05, step=0.25)
+    res = sh.extract(vol, prm)
+    counts = gather_counts(int(res.n_points), int(res.n_cells), dev, None)       # all_gather_into_tensor over RCCL
+    assert counts.shape == (1, 2) and counts[0, 0] == res.n_points and counts[0, 1] == res.n_cells
+    reqs, keep = exchange_halos(vol, 0, n, 0, n, 0, 1, None, wait=False)          # no neighbours: nothing posted
+    assert not reqs
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    res2 = sh.extract(vol, prm)                                                   # the library still works after RCCL ran
+    assert (res2.n_points, res2.n_cells) == (res.n_points, res.n_cells) and res.n_points > 1000
+    want = ex.download()
+    # the one-wait step exactly as N ranks run it, with RCCL's all-gather of the rows in device memory (a world of one:
+    # the collective, the two events that order it against the library's stream, the offset summed on the device) --
+    # sized by a host read on a fresh context, then blind
+    ex2 = pkg.Extractor(0)
+    sh2 = ShardedExtractor(ex2, (n, n, n), np.float32, 0, 1, params=prm, thin_halo=False)
+    for _ in range(3):
+        r3 = sh2._extract_step(vol, prm, False)
+        got = ex2.download()
+        assert (r3.n_points, r3.n_cells) == (res.n_points, res.n_cells)
+        assert np.array_equal(got.cells, want.cells) and np.array_equal(got.points.view(np.uint32), want.points.view(np.uint32))
+        assert sh2.stats["collectives"] == 1 and sh2.stats["host_syncs"] == 1, sh2.stats
+        sh2.stats = {"halo_bytes": 0, "halo_bit_bytes": 0, "host_syncs": 0, "collectives": 0, "escaped": 0, "deep_halo_fetched": False}
+    ex2.close()
+    print("RCCL_SMOKE_OK", int(res.n_points), int(res.n_cells))
+finally:
+    dist.destroy_process_group()
+"""
+
+
 def test_rccl_and_library_share_one_process(tmp_path):
     """One rank, backend nccl (= RCCL): process-group init, all-gather of the counts on device tensors, all-reduce
     and barrier next to libcuberille_hip.so in the same process (both must bind the HIP runtime torch ships); and the
