@@ -141,7 +141,6 @@ struct Tuning {
   // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass
   // (proj_waves 0: 16 384, or 65 536 waves dealing batches of 64 where walks are short -- see launch_project)
   int proj_chunk = 0, proj_waves = 0, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
-  int proj_producer = 0;      // 1: the walk with a producer wave per workgroup (k_project_pw: A/B of round 5's form)
   int count_no_fold = 0;      // 1: the block scan always as a launch of its own (A/B of the scan folded into small count launches)
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };

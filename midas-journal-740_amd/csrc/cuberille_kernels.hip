@@ -2623,15 +2623,14 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         o[counter] = overlap;
       }
       bool literal = !cellFinite || forceLiteral;
-      {
-        // the weights are >= 0, so the rounded partial sums never decrease: if the sum of the first seven is
-        // below 1 none of them is 1 (a sum that is not below 1 -- or NaN -- takes the literal loop, which is
-        // always right)
-        double t = o[0];
-#pragma unroll
-        for (int counter = 1; counter < 7; counter++) t += o[counter];
-        literal |= !(t < 1.0);
-      }
+      // Can a partial sum of the weights be exactly 1.0 before the last term?  The weights are >= 0, so the rounded partial
+      // sums never decrease and none exceeds the rounded sum of the first seven, S7.  The eight weights are the rounded
+      // products of (d, fl(1 - d)) pairs, each pair summing to 1 within 2^-53 and every product within 2^-52 of exact: all
+      // eight add up to 1 within 1e-15, so S7 <= 1 + 1e-15 - o[7], and seven rounded additions add at most 8e-16 more.
+      // With o[7] > 1e-14 every partial sum is below 1: ONE comparison instead of six dependent f64 additions per pass
+      // (round 5; ~3 % of a pass).  A last weight that small -- a vertex within a hair of a cell face -- or a NaN takes the
+      // literal loop, which is always right.
+      literal |= !(o[7] > 1e-14);
       double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
       if (!literal) {
 #pragma unroll
@@ -2722,372 +2721,6 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
   if (lane == 0 && stopStepsW) atomicAdd(&tot->stopSteps, (u64)stopStepsW);
   if (MODE == 1 && lane == 0 && escapedW) atomicOr(&tot->err, (u32)ERRF_ESCAPE);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4, producer form (round 5; the one shape of the refilling walk rounds 2-4 had not tried): in k_project a refill runs the
-// start-cell gather -- twelve row loads, eight site gradients, as many instructions as a pass of the walk, and two memory
-// round trips during which the walking lanes of the wave wait -- for the 16-24 lanes it brings in.  Here ONE wave of the
-// workgroup does nothing else: with all 64 lanes it gathers the start cells of the workgroup's vertices, batch after batch,
-// and leaves each vertex as a ready entry (position, cell, the 24 site-gradient components, the 8 site values) in a ring of
-// RING batches in LDS; the other three waves walk, and a refill is 40 LDS reads.  The workgroup's batches are w, w + NWG, ...
-// of 64 vertices; its walkers take entries in order through an LDS counter (`head`), so they share the stream dynamically.
-// Every wait has an exit: a walker waits for `produced` to cover the entries it claimed -- the producer never waits for a
-// walker that waits for it (a slot is re-used only when every entry of the batch RING back has been copied out, and entries
-// are claimed in order) -- and all spins are bounded (a bug ends in the err word, not in a hung GPU).
-// MODE 0 only (whole volumes and full-halo slabs); same results bit for bit: scheduling does not enter the arithmetic.
-// ---------------------------------------------------------------------------------------------
-template <class T>
-struct ProducerRing {
-  typedef typename SiteValue<T>::type SV;
-  static constexpr int NV = (int)(sizeof(SV) / 4) * 8;     // dwords of the eight site values
-  static constexpr int NF = 8 + 24 + NV;                  // dwords per entry: idx, x, y, z, kc[3], flags, G, Vd
-  static constexpr int RING = 3;
-};
-
-template <class T>
-__global__ __launch_bounds__(256, 4) void k_project_pw(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
-                                                    float *__restrict__ points, u64 nPoints, u64 nGhost, int REFILL,
-                                                    int forceLiteral, Totals *__restrict__ tot, int dyn) {
-  typedef ProducerRing<T> R;
-  typedef typename R::SV SV;
-  __shared__ u32 ring[R::RING][R::NF][64];
-  __shared__ u32 head, produced, consumed[R::RING], broken;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (dyn) {
-    if (!tot->go) return;
-    nPoints = tot->totV;
-    nGhost = tot->V0;
-  }
-  const u64 nBatches = (nPoints + 63) >> 6;
-  const u64 NWG = gridDim.x;
-  if (blockIdx.x >= nBatches) return;
-  const u32 nb = (u32)((nBatches - blockIdx.x + NWG - 1) / NWG);      // batches of this workgroup
-  const u32 totalEntries = nb * 64u;
-  if (threadIdx.x == 0) { head = 0; produced = 0; broken = 0; for (int i = 0; i < R::RING; i++) consumed[i] = 0; }
-  __syncthreads();                                   // (the only barrier: the roles part here)
-  Sampler<T> s{vox, g.nx, g.ny, g.nzb, (int)g.zglob0, (int)g.gnz};
-  const int n[3] = {g.nx, g.ny, (int)g.gnz};
-  bool unitP2I = true;
-#pragma unroll
-  for (int i = 0; i < 9; i++) unitP2I = unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
-  const int producerWave = (int)(blockIdx.x & 3);    // (rotated: which SIMD a workgroup's wave lands on is the hardware's business)
-  constexpr u32 SPIN_CAP = 1u << 24;
-  if (wv == producerWave) {
-    // ---- the producer ------------------------------------------------------------------------------------------
-    // Software-pipelined over three batches, so that a batch costs the producer its arithmetic and not two memory round
-    // trips (the first build, one batch at a time, produced 64 entries per ~4.5 us and the walkers starved: 3.1 ms against
-    // 1.19): the coordinates of batch b + 2 are on their way while the 32 pixels of batch b + 1 are, while batch b's
-    // gradients are formed and written to the ring.
-    struct Coords { float v[3]; bool valid; u64 cand; };
-    auto load_coords = [&](u32 b_, Coords &q) {
-      q.cand = (((u64)blockIdx.x + (u64)b_ * NWG) << 6) + lane;
-      q.valid = b_ < nb && q.cand < nPoints;
-      q.v[0] = q.v[1] = q.v[2] = 0.f;
-      if (q.valid) { q.v[0] = points[3 * q.cand]; q.v[1] = points[3 * q.cand + 1]; q.v[2] = points[3 * q.cand + 2]; }
-    };
-    // the 32 pixels of a unit cell (the clamped address form: the same pixels as the immediate-offset form for an interior
-    // cell); any other cell -- on or beyond the image border -- is left to gather_cell when the batch is finished
-    auto issue_gather = [&](Coords &q, Cell8 &c, T (&V)[4][4][4], bool &unit) {
-      unit = false;
-      if (q.valid) q.valid = !(q.cand < nGhost && q.v[0] != q.v[0]);       // (see k_project: the ghost slice's bottom plane)
-      if (!q.valid) return;
-      const double p[3] = {(double)q.v[0], (double)q.v[1], (double)q.v[2]};
-      make_cell(geo, unitP2I, n, p, c);
-      unit = c.lo[0] + 1 == c.hi[0] && c.lo[1] + 1 == c.hi[1] && c.lo[2] + 1 == c.hi[2];
-      if (!unit) return;
-      int xs[4], ys[4], zs[4];
-      xs[0] = c.lo[0] > 0 ? c.lo[0] - 1 : 0;  xs[1] = c.lo[0];  xs[2] = c.hi[0];  xs[3] = c.hi[0] < s.nx - 1 ? c.hi[0] + 1 : s.nx - 1;
-      ys[0] = c.lo[1] > 0 ? c.lo[1] - 1 : 0;  ys[1] = c.lo[1];  ys[2] = c.hi[1];  ys[3] = c.hi[1] < s.ny - 1 ? c.hi[1] + 1 : s.ny - 1;
-      zs[0] = s.zlocal(c.lo[2] > 0 ? c.lo[2] - 1 : 0);  zs[1] = s.zlocal(c.lo[2]);  zs[2] = s.zlocal(c.hi[2]);
-      zs[3] = s.zlocal(c.hi[2] < s.gnz - 1 ? c.hi[2] + 1 : s.gnz - 1);
-#pragma unroll
-      for (int zi = 0; zi < 4; zi++)
-#pragma unroll
-        for (int yi = 0; yi < 4; yi++) {
-          const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2);
-          if (!zin && !yin) continue;
-          const T *row = s.vox + ((size_t)zs[zi] * s.ny + ys[yi]) * s.nx;
-          if (zin && yin) {
-#pragma unroll
-            for (int xi = 0; xi < 4; xi++) V[zi][yi][xi] = row[xs[xi]];
-          } else {
-            V[zi][yi][1] = row[xs[1]];
-            V[zi][yi][2] = row[xs[2]];
-          }
-        }
-    };
-    Coords q0, q1, q2;
-    Cell8 cPrev, cNew;
-    T Vprev[4][4][4], Vnew[4][4][4];
-    bool unitPrev = false, unitNew = false;
-    load_coords(0, q1);
-    load_coords(1, q2);
-    q0 = q1;                                         // (placeholder: batch -1 does not exist)
-    q0.valid = false;
-    for (u32 b = 0; b <= nb; b++) {
-      // (1) batch b: its coordinates are here; the pixels go on their way.  (2) batch b + 2: its coordinates go on their way.
-      Coords qb = q1;
-      if (b < nb) issue_gather(qb, cNew, Vnew, unitNew);
-      q1 = q2;
-      load_coords(b + 2, q2);
-      // (3) batch b - 1: its pixels are here
-      if (b > 0) {
-        const u32 pb = b - 1;
-        const int slot = (int)(pb % R::RING);
-        float G[8][3];
-        SV Vd[8];
-        int kc[3] = {-2, -2, -2};
-        bool cellFinite = false;
-        if (q0.valid) {
-          if (unitPrev) cell_gradients<T, false>(geo, dirIdentity != 0, Vprev, G, Vd);
-          else gather_cell<T, false>(s, geo, dirIdentity != 0, cPrev, G, Vd);
-          float tf = 0.0f;
-          double td = 0.0;
-#pragma unroll
-          for (int counter = 0; counter < 8; counter++) {
-            td = __builtin_fma((double)Vd[counter], 0.0, td);
-#pragma unroll
-            for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
-          }
-          cellFinite = (tf == 0.0f) && (td == 0.0);
-          if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, cPrev, G, Vd);
-#pragma unroll
-          for (int k = 0; k < 3; k++) kc[k] = cPrev.bc[k];
-        }
-        if (pb >= (u32)R::RING) {
-          const u32 want = 64u * (pb / R::RING);
-          u32 spins = 0;
-          while (__hip_atomic_load(&consumed[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-              if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
-              return;
-            }
-          }
-        }
-        u32 (*e)[64] = ring[slot];
-        e[0][lane] = (u32)q0.cand;
-        e[1][lane] = __float_as_uint(q0.v[0]); e[2][lane] = __float_as_uint(q0.v[1]); e[3][lane] = __float_as_uint(q0.v[2]);
-        e[4][lane] = (u32)kc[0]; e[5][lane] = (u32)kc[1]; e[6][lane] = (u32)kc[2];
-        e[7][lane] = (q0.valid ? 1u : 0u) | (cellFinite ? 2u : 0u);
-        if (q0.valid) {
-#pragma unroll
-          for (int counter = 0; counter < 8; counter++) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) e[8 + counter * 3 + k][lane] = __float_as_uint(G[counter][k]);
-            if constexpr (sizeof(SV) == 4) {
-              e[32 + counter][lane] = __float_as_uint((float)Vd[counter]);
-            } else {
-              const unsigned long long bits64 = (unsigned long long)__double_as_longlong((double)Vd[counter]);
-              e[32 + 2 * counter][lane] = (u32)bits64;
-              e[33 + 2 * counter][lane] = (u32)(bits64 >> 32);
-            }
-          }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the entries are in LDS
-        if (lane == 0) __hip_atomic_store(&produced, pb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      // roll: batch b becomes the one whose pixels are awaited
-      q0 = qb;
-      cPrev = cNew;
-      unitPrev = unitNew;
-#pragma unroll
-      for (int zi = 0; zi < 4; zi++)
-#pragma unroll
-        for (int yi = 0; yi < 4; yi++)
-#pragma unroll
-          for (int xi = 0; xi < 4; xi++) {
-            const bool zin = (zi == 1 || zi == 2), yin = (yi == 1 || yi == 2), xin = (xi == 1 || xi == 2);
-            if ((zin && yin) || (zin && xin) || (yin && xin)) Vprev[zi][yi][xi] = Vnew[zi][yi][xi];
-          }
-    }
-    return;
-  }
-  // ---- a walker ----------------------------------------------------------------------------------------------------
-  const double iso = (double)iso_as<T>(prm.iso, prm.isoInt);
-  unsigned myIters = 0;
-  u32 stopStepsW = 0;
-  bool active = false, more = true;
-  u64 idx = 0;
-  float vertex[3] = {0.f, 0.f, 0.f};
-  double step = 0.0;
-  unsigned numberOfSteps = 0;
-  int kc[3] = {-2, -2, -2};
-  float G[8][3];
-  SV Vd[8];
-  bool cellFinite = false;
-  for (;;) {
-    const u64 idle = __ballot(!active);
-    if (idle && more && (__popcll(idle) >= REFILL || idle == ~0ull)) {
-      const u32 take = (u32)__popcll(idle);
-      u32 base = 0;
-      if (lane == 0) base = atomicAdd(&head, take);
-      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-      if (base >= totalEntries) {
-        more = false;
-      } else {
-        const u32 endE = base + take < totalEntries ? base + take : totalEntries;
-        if (endE == totalEntries) more = false;
-        const u32 needB = (endE + 63u) >> 6;
-        u32 spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(&produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < needB) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > SPIN_CAP || __hip_atomic_load(&broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { ok = false; break; }
-        }
-        if (!ok) {                                   // (never on a healthy launch)
-          if (lane == 0) { broken = 1; atomicOr(&tot->err, (u32)ERRF_CAPACITY); }
-          more = false;
-        } else if (!active) {
-          const u32 ent = base + (u32)__popcll(idle & lowmask(lane));
-          if (ent < endE) {
-            const int slot = (int)((ent >> 6) % (u32)R::RING), off = (int)(ent & 63u);
-            u32 (*e)[64] = ring[slot];
-            const u32 flags = e[7][off];
-            idx = (u64)e[0][off];
-            vertex[0] = __uint_as_float(e[1][off]); vertex[1] = __uint_as_float(e[2][off]); vertex[2] = __uint_as_float(e[3][off]);
-            kc[0] = (int)e[4][off]; kc[1] = (int)e[5][off]; kc[2] = (int)e[6][off];
-            if (flags & 1u) {
-#pragma unroll
-              for (int counter = 0; counter < 8; counter++) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) G[counter][k] = __uint_as_float(e[8 + counter * 3 + k][off]);
-                if constexpr (sizeof(SV) == 4) {
-                  Vd[counter] = (SV)__uint_as_float(e[32 + counter][off]);
-                } else {
-                  const unsigned long long bits64 = (unsigned long long)e[32 + 2 * counter][off] | ((unsigned long long)e[33 + 2 * counter][off] << 32);
-                  Vd[counter] = (SV)__longlong_as_double((long long)bits64);
-                }
-              }
-              cellFinite = (flags & 2u) != 0;
-              step = prm.step;
-              numberOfSteps = 0;
-              active = true;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);      // the copy is in registers before the slot is given back
-            atomicAdd(&consumed[slot], 1u);
-          }
-        }
-      }
-    }
-    if (!__ballot(active)) {
-      if (!more) break;
-      continue;
-    }
-    bool bySteps = false;
-    if (active) {
-      bool done = false;
-      const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
-      Cell8 c;
-      make_cell(geo, unitP2I, n, p, c);
-      if (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2]) {
-        gather_cell<T, false>(s, geo, dirIdentity != 0, c, G, Vd);
-#pragma unroll
-        for (int k = 0; k < 3; k++) kc[k] = c.bc[k];
-        float tf = 0.0f;
-        double td = 0.0;
-#pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
-          td = __builtin_fma((double)Vd[counter], 0.0, td);
-#pragma unroll
-          for (int k = 0; k < 3; k++) tf = __builtin_fmaf(G[counter][k], 0.0f, tf);
-        }
-        cellFinite = (tf == 0.0f) && (td == 0.0);
-        if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);
-      }
-      double o[8];
-#pragma unroll
-      for (unsigned counter = 0; counter < 8; counter++) {
-        double overlap = 1.0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
-        o[counter] = overlap;
-      }
-      bool literal = !cellFinite || forceLiteral;
-      {
-        double t = o[0];
-#pragma unroll
-        for (int counter = 1; counter < 7; counter++) t += o[counter];
-        literal |= !(t < 1.0);
-      }
-      double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
-      if (!literal) {
-#pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
-          value += o[counter] * (double)Vd[counter];
-        }
-      } else {
-        double total = 0.0;
-#pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
-          if (o[counter] != 0.0 && total != 1.0) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
-            value += o[counter] * (double)Vd[counter];
-            total += o[counter];
-          }
-        }
-      }
-      done = fabs(value - iso) < prm.thr;                                     // txx:456
-      const unsigned passes = numberOfSteps + 1;
-      if (!done) {
-        float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
-        double sq = 0.0;                                                      // I8
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double e2 = (double)normal[k]; sq += e2 * e2; }
-        if (sq > 0.0 && sq < __builtin_inf()) {
-          // (k_project: the compiler's f64 sqrt and divisions written out for this argument range)
-          const double y0 = __builtin_amdgcn_rsq(sq);
-          double gs = sq * y0, hs = y0 * 0.5;
-          const double rs = __builtin_fma(-hs, gs, 0.5);
-          gs = __builtin_fma(gs, rs, gs);
-          hs = __builtin_fma(hs, rs, hs);
-          double ds = __builtin_fma(-gs, gs, sq);
-          gs = __builtin_fma(ds, hs, gs);
-          ds = __builtin_fma(-gs, gs, sq);
-          const double norm = __builtin_fma(ds, hs, gs);
-          double y = __builtin_amdgcn_rcp(norm);
-          double e2 = __builtin_fma(-norm, y, 1.0);
-          y = __builtin_fma(y, e2, y);
-          e2 = __builtin_fma(-norm, y, 1.0);
-          y = __builtin_fma(y, e2, y);
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const double x = (double)normal[k];
-            const double q0 = x * y;
-            const double r = __builtin_fma(-norm, q0, x);
-            const double q = __builtin_fma(r, y, q0);
-            normal[k] = (float)__builtin_copysign(q, x);
-          }
-        } else {
-          const double norm = sqrt(sq);
-#pragma unroll
-          for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
-        }
-        const double sign = (value < iso) ? +1.0 : -1.0;                      // txx:463
-#pragma unroll
-        for (int k = 0; k < 3; k++)                                           // txx:464-467 (I9)
-          vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
-        step *= prm.relax;                                                    // txx:468
-        done = numberOfSteps++ > prm.max_steps;                               // txx:469
-        bySteps = done && idx >= nGhost;
-      }
-      if (done) {
-        points[3 * idx] = vertex[0]; points[3 * idx + 1] = vertex[1]; points[3 * idx + 2] = vertex[2];
-        if (idx >= nGhost) myIters += passes;
-        active = false;
-      }
-    }
-    stopStepsW += (u32)__popcll(__ballot(bySteps));
-  }
-  unsigned sum = myIters;
-#pragma unroll
-  for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_down(sum, sft, 64);
-  if (lane == 0 && sum) atomicAdd(&tot->iters, (u64)sum);
-  if (lane == 0 && stopStepsW) atomicAdd(&tot->stopSteps, (u64)stopStepsW);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3802,15 +3435,6 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
     // (giving each XCD a contiguous eighth of the vertex list was measured 1.6x slower: proj_xcd stays a switch)
-    if (tn.proj_producer > 0 && mode == 0 && nPoints < 0xffffff00ull) {
-      // (the producer form: workgroups of three walking waves and one that gathers; batches of 64 per workgroup)
-      const u64 nB = (nPoints + 63) / 64;
-      const u64 wantWG = (gridWaves + 3) / 4;
-      const unsigned wgs = (unsigned)(nB < wantWG ? nB : wantWG);
-      hipLaunchKernelGGL((k_project_pw<T>), dim3(wgs), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity, w.points, nPoints,
-                         nGhost, tn.proj_refill, tn.proj_literal, w.totals, dyn);
-      return hipGetLastError();
-    }
 #define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
     hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
                        w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,  \
