@@ -1184,6 +1184,11 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
     const u32 blk = zrun ? (colRun * (u32)zrun + (u32)it) * bps + colBlock : blockIdx.x;
     const size_t w0 = (size_t)blk * COUNT_WB;
     if (w0 >= nwords) break;                       // (the same for every thread)
+    // (MODE & 16, microbench only: thread 0's clock at the phase boundaries of every block, 16 words per block in blockBase)
+    auto stamp = [&](int i) {
+      if constexpr ((MODE & 16) != 0) { if (tid == 0) blockBase[(size_t)blk * 16 + i] = (u64)clock64(); }
+    };
+    stamp(0);
     if (tid == 0) { nQueued = 0; g0InSeg = 0; lastBlock = 0; }
     long long rowFirst = 0;                        // TILED: buffer row (z * ny + y) of the tile's second row
     int slot = 1;                                  // ... and which third of the tile holds the block's own slice
@@ -1237,6 +1242,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       }
     }
     __syncthreads();
+    stamp(1);
     const long long planeBelow = (long long)((slot + 2) % 3 - slot) * TILE_PLANE, planeAbove = (long long)((slot + 1) % 3 - slot) * TILE_PLANE;
     // where word (k, y, z) of this block is read from
     auto at = [&](int k, int y, int z) -> WordPos {
@@ -1269,8 +1275,11 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       }
       cnt[i] = packed;
     }
+    stamp(2);
     __syncthreads();
+    stamp(3);
     const int nq = (MODE & 4) ? 0 : nQueued;
+    if constexpr ((MODE & 16) != 0) { if (tid == 0) blockBase[(size_t)blk * 16 + 9] = (u64)nq; }
     u32 errBits = 0;
     for (int j = tid; j < nq; j += NT) {
       const int i = queue[j];
@@ -1290,7 +1299,9 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       atomicOr(&tot->err, errBits);
       if (fold) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (on its way before this block's ticket, behind the barrier)
     }
+    stamp(4);
     __syncthreads();
+    stamp(5);
     for (int sg = wv; sg < COUNT_WB / 64; sg += NWAVES) {
       const size_t gi = w0 + sg * 64 + lane;
       const u32 packed = cnt[sg * 64 + lane];     // 0 past the end
@@ -1303,7 +1314,9 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
       const u64 vm = __ballot((packed & 0xffffu) != 0u);
       if (lane == 0) segVW[sg] = vm;
     }
+    stamp(6);
     __syncthreads();
+    stamp(7);
     if (vqueue) {
       if (wv == 1) {
         // (wave 1, beside wave 0's segment scan below: 32 segment counts -> exclusive prefix, one global atomic per block)
@@ -1341,6 +1354,7 @@ __global__ __launch_bounds__(NT, (TILED || NT > 512 ? 4 : 5)) void k_count(const
           vqueue[vbase + segVWPre[sg] + (u32)__popcll(vm & lowmask(lane))] = (u32)(w0 + sg * 64 + lane);
       }
     }
+    stamp(8);
     if (fold) {
       // the ticket, behind everything else of the block (the other waves are gone by the time it returns): wave 0's stores
       // have landed (vmcnt(0)), then one agent-scope add; the block that draws the last ticket scans the totals

@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
   Workspace w{};
   w.vox = vox;
   CK(hipMalloc(&w.bits, (nwords + (size_t)n * g.W) * 8)); CK(hipMalloc(&w.sliceOcc, n * 4)); CK(hipMalloc(&w.prefix, nwords * 4));
-  CK(hipMalloc(&w.segPre, nseg * 8)); CK(hipMalloc(&w.blockTot, nblk * 8)); CK(hipMalloc(&w.blockBase, nblk * 16));
+  CK(hipMalloc(&w.segPre, nseg * 8)); CK(hipMalloc(&w.blockTot, nblk * 8)); CK(hipMalloc(&w.blockBase, nblk * 16 * 8));
   CK(hipMalloc(&w.totals, sizeof(Totals))); CK(hipMalloc(&w.vqueue, nwords * 4));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -74,6 +74,32 @@ int main(int argc, char **argv) {
 #define KC(MODE, TILED, NT, VQ) hipLaunchKernelGGL((k_count<MODE, TILED, NT>), dim3(blocks), dim3(NT), 0, 0, w.bits, w.sliceOcc, g, nwords, 1, \
                                                     w.prefix, w.segPre, w.blockTot, VQ, w.totals, 0, w.blockBase, Gate{}, 0)
   printf("n %d wavelength %.0f\n", n, wl);
+  {
+    // where a block's time goes (round-4 review: the sphere's 0.03 ms for 1024 blocks "unexplained"): thread 0's clock at the
+    // phase boundaries of every block (MODE 16), medians over the blocks, in shader cycles
+    CK(hipMemsetAsync(w.totals, 0, sizeof(Totals), 0));
+    CK(hipMemsetAsync(w.blockBase, 0, nblk * 16 * 8, 0));
+    KC(16, false, 256, w.vqueue);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(nblk * 16);
+    CK(hipMemcpy(st.data(), w.blockBase, nblk * 16 * 8, hipMemcpyDeviceToHost));
+    const char *names[8] = {"start -> first barrier", "phase 1 (faces, 8 words per thread)", "barrier", "phase 2 (corner logic of queued words)",
+                            "barrier", "phase 3 (wave scans, prefix stores)", "barrier", "segment scan + queue flush"};
+    unsigned long long t0min = ~0ull, t8max = 0;
+    for (size_t b = 0; b < nblk; b++) { t0min = std::min(t0min, st[b * 16]); t8max = std::max(t8max, st[b * 16 + 8]); }
+    printf("phase stamps, untiled 256 (cycles; median / 90th percentile over %zu blocks; kernel span %llu cycles)\n", nblk, t8max - t0min);
+    for (int ph = 0; ph < 8; ph++) {
+      std::vector<unsigned long long> d(nblk);
+      for (size_t b = 0; b < nblk; b++) d[b] = st[b * 16 + ph + 1] - st[b * 16 + ph];
+      std::sort(d.begin(), d.end());
+      printf("  %-44s %8llu / %8llu\n", names[ph], d[nblk / 2], d[nblk * 9 / 10]);
+    }
+    std::vector<unsigned long long> q(nblk), life(nblk), start(nblk);
+    for (size_t b = 0; b < nblk; b++) { q[b] = st[b * 16 + 9]; life[b] = st[b * 16 + 8] - st[b * 16]; start[b] = st[b * 16] - t0min; }
+    std::sort(q.begin(), q.end()); std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end());
+    printf("  queued words per block: median %llu, max %llu; block lifetime median %llu, max %llu; block start after the first: median %llu, max %llu\n",
+           q[nblk / 2], q[nblk - 1], life[nblk / 2], life[nblk - 1], start[nblk / 2], start[nblk - 1]);
+  }
   timeIt([&] { KC(0, false, 256, w.vqueue); }, "untiled: everything");
   timeIt([&] { KC(0, false, 256, (u32 *)nullptr); }, "untiled: no vertex-word queue");
   timeIt([&] { KC(2, false, 256, w.vqueue); }, "untiled: no block-level scans / queue");
