@@ -527,6 +527,12 @@ int count_launch(cuberille_ctx *c, const Gate &gate) {
   // (the LDS-tiled form pays where most words carry surface -- 2048^3 noise -- and costs where few do: it stages every
   //  row, a sparse block's untiled form skips whole words; the previous extraction's density decides)
   int tiled = c->tune.count_variant >= 0 ? c->tune.count_variant : (c->haveHistory && c->histDense ? 3 : 0);
+  // A launch whose blocks are all resident at once is a block's latency, whatever the field: eight dependent trips to memory per
+  // thread for the faces (2600 cycles each, profiles/microbench/r5_count_phase_stamps.log) and two or three more for the corner
+  // logic from memory; the LDS tile (one block per workgroup) makes that one coalesced copy -- 512^3 sphere 0.0352 -> 0.0309 ms,
+  // 512^3 Marschner-Lobb 0.0466 -> 0.0388; with several rounds of blocks (768^3: 3456) the form that skips empty words wins again.
+  if (c->tune.count_variant < 0 && tiled == 0 && (c->nwords + COUNT_WB - 1) / COUNT_WB <= 1280 && (c->nwords + COUNT_WB - 1) / COUNT_WB > 64)
+    tiled = 2;
   if (c->tune.count_variant < 0 && !c->haveHistory && c->nwords >= (1u << 22) && c->g.wShift >= 0) {
     // no previous extraction to go by (round-4 review: a one-shot caller of a dense field paid 2.3 ms for a 1.2 ms count):
     // a sample of THIS volume's bit volume picks the form -- one small launch and one more wait, on a context's first
@@ -810,7 +816,9 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
     // (walks that end after two or three passes -- a noise field -- leave the kernel bound by its gathers, which a refill
     //  issues for the few lanes it fills: such fields refill only empty waves.  Scheduling only: results never depend on it.)
     Tuning tn = c->tune;
-    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : 16;
+    // (long walks refill at 32 idle lanes: 1.161-1.166 ms against 1.178-1.192 at 16 on the headline field, three boxes, round 5;
+    //  24 and 40 are no better, 48 loses 8 %)
+    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : 32;
     if (c->voxelHaloEvent) {                 // the first reader of the halo's voxels
       HIP_TRY(c, hipStreamWaitEvent(s, c->voxelHaloEvent, 0));
       c->voxelHaloEvent = nullptr;

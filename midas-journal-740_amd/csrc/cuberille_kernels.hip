@@ -183,16 +183,19 @@ __device__ __forceinline__ u64 group_or(u64 part) {
 // write-through (sc1) stores in one burst; the grid is two workgroups per CU.
 constexpr int SPAN_WORDS = 4096;
 
-template <class T>
+// SPAN: words per span -- SPAN_WORDS, or a quarter of it where the volume is fewer than two rounds of such spans (a 512^3 float32
+// volume is ONE: every workgroup then ends in its 32 KiB store burst at the same moment, behind the last read; with four
+// rounds of 8 KiB bursts the stores of a round leave beside the next round's reads)
+template <class T, int SPAN = SPAN_WORDS>
 __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox, u64 *__restrict__ bits, u64 nspans,
                                                        double isoD, long long isoI, u32 *__restrict__ sliceOcc,
                                                        int lgWordsPerSlice) {
   constexpr int U = 4;
   constexpr int VPL = 16 / sizeof(T);
   constexpr int LPW = 64 / VPL;
-  constexpr int TRIPS = SPAN_WORDS / (4 * U * VPL);      // trips of U KiB per wave and span
+  constexpr int TRIPS = SPAN / (4 * U * VPL);      // trips of U KiB per wave and span
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) u64 stage[SPAN_WORDS];
+  __shared__ __attribute__((aligned(16))) u64 stage[SPAN];
   const T iso = iso_as<T>(isoD, isoI);
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -224,9 +227,9 @@ __global__ __launch_bounds__(256) void k_classify_span(const T *__restrict__ vox
       pack(r, tl);
     }
     __syncthreads();
-    const u64 w0 = sp * (u64)SPAN_WORDS;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(bits + w0, 0, SPAN_WORDS * 8, 0x00020000);
-    for (int i = threadIdx.x * 2; i < SPAN_WORDS; i += 512) {
+    const u64 w0 = sp * (u64)SPAN;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(bits + w0, 0, SPAN * 8, 0x00020000);
+    for (int i = threadIdx.x * 2; i < SPAN; i += 512) {
       const u32x4 v = *reinterpret_cast<const u32x4 *>(&stage[i]);
       __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, i * 8, 0, 16);          // aux 16 = sc1: write-through
       if (lgWordsPerSlice > 0) {
@@ -3102,6 +3105,15 @@ hipError_t launch_classify(int pixel_type, const Workspace &wAll, const Grid &g,
       // large ranges: whole spans through the staged write-through kernel (below ~256 MiB the caches absorb the
       // word stores and more, smaller workgroups fill the chip better)
       u64 spanWords = 0;
+      const u64 want0 = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;
+      if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20) && nwordsAll / SPAN_WORDS < 2 * want0 &&
+          nwordsAll % (SPAN_WORDS / 4) == 0 && !tn.classify_keep_tail) {
+        // fewer than two rounds of whole spans: quarter spans, four times the rounds
+        const u64 nspans = nwordsAll / (SPAN_WORDS / 4);
+        const unsigned blocks = (unsigned)(nspans < want0 ? nspans : want0);
+        hipLaunchKernelGGL((k_classify_span<T, SPAN_WORDS / 4>), dim3(blocks), dim3(256), 0, s, vox, w.bits, nspans, iso, isoI, w.sliceOcc, lg);
+        spanWords = nwordsAll;
+      } else
       if (tn.classify_variant == 0 && nwordsAll * 64 * sizeof(T) >= (256ull << 20)) {
         u64 nspans = nwordsAll / SPAN_WORDS;
         const u64 want = tn.classify_grid > 0 ? (u64)tn.classify_grid : 512;   // two workgroups per CU

@@ -214,6 +214,15 @@ def test_span_sweep_every_pixel_type(pkg, extractor, dtype, shape):
     for z0 in range(0, nz, 32):
         bits = ((words[z0:z0 + 32, :, :, None] >> shifts) & 1).bool().reshape(-1, ny, nx)
         assert torch.equal(bits, inside[z0:z0 + 32]), "packed bits differ from the threshold in slices %d.." % z0
+    # (round 5: volumes of fewer than two rounds of 4096-word spans -- all of these -- are swept in quarter spans; the whole
+    #  spans of larger volumes, forced here, pack the same words)
+    extractor.debug_option("classify_keep_tail", 1)
+    try:
+        res = extractor.extract_device(dev.data_ptr(), pkg.make_desc(dtype, (nx, ny, nz)), pkg.make_params(iso, triangles=False, project=False))
+        assert (int(res.n_points), int(res.n_cells)) == (want_pts, want_quads)
+        assert torch.equal(torch.from_numpy(extractor.debug_bits((nx, ny, nz)).view(np.int64)).cuda(), words)
+    finally:
+        extractor.debug_option("defaults", 0)
     del vol, dev, inside, words
 
 
