@@ -52,6 +52,25 @@ def extractor(pkg):
     """One GPU context shared by the -m gpu tests (they run in one process)."""
     pkg._abi.build()
     ex = pkg.Extractor(0)
+    # The library works on a NON-BLOCKING stream of its own: a volume that torch has just generated or copied on ITS stream is
+    # only ordered before the extraction by an event the caller hands over (cuberille_slab::voxels_ready_event) or by a wait.
+    # The tests that generate volumes on the GPU mostly do neither -- they used to pass because a workspace that had to grow
+    # (hipFree) synchronised the device on the way -- so the shared extractor waits for torch here, except where a test hands
+    # over events of its own (those test exactly that ordering).
+    def waits_for_torch(method):
+        inner = getattr(ex, method)
+
+        def call(*args, **kw):
+            handed_over = any(getattr(a, "voxels_ready_event", None) or getattr(a, "halo_ready_event", None)
+                              for a in list(args) + list(kw.values()))
+            if not handed_over and "torch" in sys.modules:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            return inner(*args, **kw)
+        setattr(ex, method, call)
+    for m in ("extract_device", "count", "step_begin", "step_classify"):
+        waits_for_torch(m)
     yield ex
     ex.close()
 
