@@ -149,10 +149,67 @@ private:
   bool m_Malloced;
 };
 
+// Does container C hand out a std::vector of E through CastToSTLContainer()?  itk::VectorContainer (DefaultStaticMeshTraits,
+// the reference's mesh type) does; itk::MapContainer (DefaultDynamicMeshTraits) hands out a std::map: meshes of such traits are
+// filled element by element, the way the reference does it (round-4 advisor finding: the bulk fill alone did not compile there).
+template <class C, class E> struct CastsToVectorOf
+{
+  template <class U> static char Probe(U *, typename std::enable_if<std::is_same<decltype(std::declval<U &>().CastToSTLContainer()),
+                                                                                   std::vector<E> &>::value>::type * = 0);
+  template <class U> static long Probe(...);
+  static const bool Value = sizeof(Probe<C>(static_cast<C *>(0))) == sizeof(char);
+};
+template <bool> struct FillTag {};
+
+// The reference's own loop (txx:309-329): one heap object per cell, handed to the mesh, which owns and later deletes it.
+template <class TMesh, class TCell, unsigned int K>
+void FillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells, FillTag<false>)
+{
+  typedef typename TMesh::PointIdentifier PointIdentifier;
+  typedef typename TMesh::CellAutoPointer CellAutoPointer;
+  for (uint64_t c = 0; c < nCells; c++)
+    {
+    PointIdentifier v[K];
+    for (unsigned int k = 0; k < K; k++) v[k] = static_cast<PointIdentifier>(ids[K * c + k]);
+    CellAutoPointer cell;
+    TCell *one = new TCell;
+    one->SetPointIds(v);
+    cell.TakeOwnership(one);
+    mesh->SetCell(static_cast<typename TMesh::CellIdentifier>(c), cell);
+    }
+}
+
+template <class TMesh>
+void FillPoints(TMesh *mesh, const float *src, uint64_t nPoints, FillTag<false>)
+{
+  typename TMesh::PointType p;
+  for (uint64_t i = 0; i < nPoints; i++)
+    {
+    p[0] = src[3 * i]; p[1] = src[3 * i + 1]; p[2] = src[3 * i + 2];
+    mesh->SetPoint(static_cast<typename TMesh::PointIdentifier>(i), p);      // txx:275
+    }
+}
+
+// points by value, straight into the vector's elements
+template <class TMesh>
+void FillPoints(TMesh *mesh, const float *src, uint64_t nPoints, FillTag<true>)
+{
+  typedef typename TMesh::PointType PointType;
+  std::vector<PointType> &pc = mesh->GetPoints()->CastToSTLContainer();
+  pc.resize(static_cast<size_t>(nPoints));
+  struct Fill
+    {
+    PointType *dst; const float *src;
+    void operator()(uint64_t i0, uint64_t i1) const
+      { for (uint64_t i = i0; i < i1; i++) { dst[i][0] = src[3 * i]; dst[i][1] = src[3 * i + 1]; dst[i][2] = src[3 * i + 2]; } }
+    } fp = {nPoints ? &pc[0] : 0, src};
+  ParallelRanges(nPoints, fp);
+}
+
 // Bulk form of the loop at txx:309-329: all cells of the mesh constructed in one slab, the cell container filled with
 // pointers into it by a few threads.
 template <class TMesh, class TCell, unsigned int K>
-void BulkFillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells)
+void FillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells, FillTag<true>)
 {
   typedef typename TMesh::CellType BaseCellType;
   typedef typename TMesh::PointIdentifier PointIdentifier;
@@ -544,21 +601,17 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
     }
 
   const double fillStart = cuberille_detail::WallSeconds();
-  // points by value, straight into the container's elements
-  {
-    std::vector<PointType> &pc = mesh->GetPoints()->CastToSTLContainer();
-    pc.resize(static_cast<size_t>(res.n_points));
-    struct FillPoints
-      {
-      PointType *dst; const float *src;
-      void operator()(uint64_t i0, uint64_t i1) const
-        { for (uint64_t i = i0; i < i1; i++) { dst[i][0] = src[3 * i]; dst[i][1] = src[3 * i + 1]; dst[i][2] = src[3 * i + 2]; } }
-      } fp = {res.n_points ? &pc[0] : 0, points};
-    cuberille_detail::ParallelRanges(res.n_points, fp);
-  }
-  // all cells in one slab that lives and dies with the mesh (CellSlab above); the mesh holds pointers into it
-  if (res.verts_per_cell == 3) cuberille_detail::BulkFillCells<OutputMeshType, TriangleCellType, 3>(mesh.GetPointer(), cells, res.n_cells);
-  else cuberille_detail::BulkFillCells<OutputMeshType, QuadrilateralCellType, 4>(mesh.GetPointer(), cells, res.n_cells);
+  // Meshes whose containers are vectors (the reference's mesh type and every DefaultStaticMeshTraits mesh): points straight
+  // into the vector's elements, all cells in one slab that lives and dies with the mesh (CellSlab above); any other
+  // container -- DefaultDynamicMeshTraits' maps -- element by element through SetPoint / SetCell like the reference
+  typedef typename OutputMeshType::PointsContainer PointsContainerType;
+  typedef typename OutputMeshType::CellsContainer CellsContainerType;
+  typedef typename OutputMeshType::CellType BaseCellType;
+  cuberille_detail::FillPoints(mesh.GetPointer(), points, res.n_points,
+                               cuberille_detail::FillTag<cuberille_detail::CastsToVectorOf<PointsContainerType, PointType>::Value>());
+  typedef cuberille_detail::FillTag<cuberille_detail::CastsToVectorOf<CellsContainerType, BaseCellType *>::Value> CellFillTag;
+  if (res.verts_per_cell == 3) cuberille_detail::FillCells<OutputMeshType, TriangleCellType, 3>(mesh.GetPointer(), cells, res.n_cells, CellFillTag());
+  else cuberille_detail::FillCells<OutputMeshType, QuadrilateralCellType, 4>(mesh.GetPointer(), cells, res.n_cells, CellFillTag());
   m_LastMeshFillSeconds = cuberille_detail::WallSeconds() - fillStart;
 }
 

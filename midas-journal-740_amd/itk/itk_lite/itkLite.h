@@ -447,6 +447,50 @@ protected:
 // ------------------------------------------------------------------------------------------
 // Mesh, cells
 // ------------------------------------------------------------------------------------------
+template <class TId, class TElement> class VectorContainer : public Object {
+public:
+  typedef VectorContainer Self;
+  typedef SmartPointer<Self> Pointer;
+  itkNewMacro(Self);
+  typedef TId ElementIdentifier;
+  typedef TElement Element;
+  void InsertElement(ElementIdentifier id, const Element &e) { if (m_V.size() <= id) m_V.resize(id + 1); m_V[id] = e; }
+  const Element &GetElement(ElementIdentifier id) const { return m_V[id]; }
+  Element &ElementAt(ElementIdentifier id) { return m_V[id]; }
+  void Reserve(ElementIdentifier n) { m_V.reserve(n); }
+  ElementIdentifier Size() const { return m_V.size(); }
+  void Initialize() { m_V.clear(); }
+  std::vector<Element> &CastToSTLContainer() { return m_V; }
+protected:
+  VectorContainer() {}
+  std::vector<Element> m_V;
+};
+
+// itk::MapContainer as DefaultDynamicMeshTraits uses it: identifier -> element in a std::map (no contiguous storage: a
+// filter that fills meshes in bulk has to take the element-by-element road for it)
+template <class TId, class TElement> class MapContainer : public Object {
+public:
+  typedef MapContainer Self;
+  typedef SmartPointer<Self> Pointer;
+  itkNewMacro(Self);
+  typedef TId ElementIdentifier;
+  typedef TElement Element;
+  typedef std::map<TId, TElement> STLContainerType;
+  void InsertElement(ElementIdentifier id, const Element &e) { m_M[id] = e; }
+  const Element &GetElement(ElementIdentifier id) const { return m_M.find(id)->second; }
+  Element &ElementAt(ElementIdentifier id) { return m_M[id]; }
+  bool IndexExists(ElementIdentifier id) const { return m_M.count(id) != 0; }
+  void Reserve(ElementIdentifier) {}
+  ElementIdentifier Size() const { return m_M.size(); }
+  void Initialize() { m_M.clear(); }
+  STLContainerType &CastToSTLContainer() { return m_M; }
+protected:
+  MapContainer() {}
+  STLContainerType m_M;
+};
+
+template <class TPixelType, class TCellTraits> class CellInterface;
+
 template <class TPixelType, unsigned int VPointDimension = 3, unsigned int VMaxTopologicalDimension = VPointDimension,
           class TCoordRep = float, class TInterpolationWeight = float, class TCellPixelType = TPixelType>
 class DefaultStaticMeshTraits {
@@ -466,6 +510,20 @@ public:
     typedef PointIdentifier *PointIdIterator;
     typedef const PointIdentifier *PointIdConstIterator;
   };
+  typedef CellInterface<CellPixelType, CellTraits> CellType;
+  typedef VectorContainer<PointIdentifier, PointType> PointsContainer;
+  typedef VectorContainer<CellIdentifier, CellType *> CellsContainer;
+};
+
+// itk::DefaultDynamicMeshTraits: the same names, points and cells in MapContainers
+template <class TPixelType, unsigned int VPointDimension = 3, unsigned int VMaxTopologicalDimension = VPointDimension,
+          class TCoordRep = float, class TInterpolationWeight = float, class TCellPixelType = TPixelType>
+class DefaultDynamicMeshTraits
+  : public DefaultStaticMeshTraits<TPixelType, VPointDimension, VMaxTopologicalDimension, TCoordRep, TInterpolationWeight, TCellPixelType> {
+  typedef DefaultStaticMeshTraits<TPixelType, VPointDimension, VMaxTopologicalDimension, TCoordRep, TInterpolationWeight, TCellPixelType> Base;
+public:
+  typedef MapContainer<typename Base::PointIdentifier, typename Base::PointType> PointsContainer;
+  typedef MapContainer<typename Base::CellIdentifier, typename Base::CellType *> CellsContainer;
 };
 
 template <class TPixelType, class TCellTraits> class CellInterface {
@@ -517,24 +575,6 @@ protected:
 template <class TCellInterface> class TriangleCell : public FixedCell<TCellInterface, 3> {};
 template <class TCellInterface> class QuadrilateralCell : public FixedCell<TCellInterface, 4> {};
 
-template <class TId, class TElement> class VectorContainer : public Object {
-public:
-  typedef VectorContainer Self;
-  typedef SmartPointer<Self> Pointer;
-  itkNewMacro(Self);
-  typedef TId ElementIdentifier;
-  typedef TElement Element;
-  void InsertElement(ElementIdentifier id, const Element &e) { if (m_V.size() <= id) m_V.resize(id + 1); m_V[id] = e; }
-  const Element &GetElement(ElementIdentifier id) const { return m_V[id]; }
-  Element &ElementAt(ElementIdentifier id) { return m_V[id]; }
-  void Reserve(ElementIdentifier n) { m_V.reserve(n); }
-  ElementIdentifier Size() const { return m_V.size(); }
-  void Initialize() { m_V.clear(); }
-  std::vector<Element> &CastToSTLContainer() { return m_V; }
-protected:
-  VectorContainer() {}
-  std::vector<Element> m_V;
-};
 
 template <class TPixelType, unsigned int VDimension = 3,
           class TMeshTraits = DefaultStaticMeshTraits<TPixelType, VDimension, VDimension> >
@@ -555,9 +595,9 @@ public:
   typedef typename MeshTraits::PointType PointType;
   typedef CellInterface<typename MeshTraits::CellPixelType, CellTraits> CellType;
   typedef typename CellType::CellAutoPointer CellAutoPointer;
-  typedef VectorContainer<PointIdentifier, PointType> PointsContainer;
+  typedef typename MeshTraits::PointsContainer PointsContainer;
   typedef typename PointsContainer::Pointer PointsContainerPointer;
-  typedef VectorContainer<CellIdentifier, CellType *> CellsContainer;
+  typedef typename MeshTraits::CellsContainer CellsContainer;
   typedef typename CellsContainer::Pointer CellsContainerPointer;
 
   PointsContainer *GetPoints() { if (m_Points.IsNull()) m_Points = PointsContainer::New(); return m_Points; }
@@ -565,7 +605,7 @@ public:
   unsigned long GetNumberOfPoints() const { return m_Points.IsNull() ? 0 : m_Points->Size(); }
   unsigned long GetNumberOfCells() const { return m_Cells.IsNull() ? 0 : m_Cells->Size(); }
   void SetPoint(PointIdentifier id, const PointType &p) { GetPoints()->InsertElement(id, p); }
-  bool GetPoint(PointIdentifier id, PointType *p) const { if (m_Points.IsNull() || id >= m_Points->Size()) return false; *p = m_Points->GetElement(id); return true; }
+  bool GetPoint(PointIdentifier id, PointType *p) const { if (m_Points.IsNull() || id >= m_Points->Size()) return false; *p = m_Points->GetElement(id); return true; }   // (ids are dense here: 0 .. Size() - 1)
   void SetCells(CellsContainer *cells) { if (m_Cells.GetPointer() != cells) { ReleaseCellsMemory(); m_Cells = cells; this->Modified(); } }
   // How the cell objects were allocated, hence who frees them (names and meaning of itk::Mesh::ReleaseCellsMemory):
   //   CellsAllocatedDynamicallyCellByCell  each cell came from its own `new` and the mesh deletes it (txx:310-313);

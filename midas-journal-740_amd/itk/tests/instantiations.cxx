@@ -9,6 +9,7 @@
 
 #include "itkImage.h"
 #include "itkMesh.h"
+#include "itkDefaultDynamicMeshTraits.h"
 #include "itkCuberilleImageToMeshFilter.h"
 
 // A user's interpolator type (TInterpolator): a distinct class the filter has never seen.
@@ -219,12 +220,77 @@ static bool mesh_outlives_the_filter()
   return true;
 }
 
+// A mesh whose containers are NOT vectors (itk::DefaultDynamicMeshTraits: MapContainers): the filter fills it element by
+// element through SetPoint / SetCell, as the reference does (txx:275, 309-329), and the mesh equals the static-traits one
+// (round-4 advisor finding: the bulk fill alone did not compile for such a mesh).
+static bool dynamic_traits_mesh_equals_static()
+{
+  typedef itk::Image<unsigned char, 3> ImageType;
+  typedef itk::Mesh<unsigned char, 3> StaticMesh;
+  typedef itk::Mesh<unsigned char, 3, itk::DefaultDynamicMeshTraits<unsigned char, 3, 3> > DynamicMesh;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, StaticMesh> StaticFilter;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, DynamicMesh> DynamicFilter;
+  const int n = 20;
+  ImageType::Pointer image = ImageType::New();
+  ImageType::RegionType region;
+  ImageType::IndexType start;
+  ImageType::SizeType size;
+  start.Fill(0);
+  size.Fill(n);
+  region.SetIndex(start);
+  region.SetSize(size);
+  image->SetRegions(region);
+  image->Allocate();
+  for (int z = 0; z < n; z++)
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++)
+        {
+        ImageType::IndexType idx;
+        idx[0] = x; idx[1] = y; idx[2] = z;
+        const double r = std::sqrt((x - 9.3) * (x - 9.3) + (y - 9.6) * (y - 9.6) + (z - 9.1) * (z - 9.1));
+        image->SetPixel(idx, static_cast<unsigned char>(r < 6.0 ? 200 : 0));
+        }
+  bool same = true;
+  for (int tri = 0; tri < 2 && same; tri++)
+    {
+    StaticFilter::Pointer a = StaticFilter::New();
+    DynamicFilter::Pointer b = DynamicFilter::New();
+    a->SetInput(image); b->SetInput(image);
+    a->SetIsoSurfaceValue(100); b->SetIsoSurfaceValue(100);
+    a->SetGenerateTriangleFaces(tri != 0); b->SetGenerateTriangleFaces(tri != 0);
+    a->Update(); b->Update();
+    b->Update();                                      // a second fill of the same dynamic mesh replaces the first
+    StaticMesh::Pointer ma = a->GetOutput();
+    DynamicMesh::Pointer mb = b->GetOutput();
+    same = ma->GetNumberOfPoints() == mb->GetNumberOfPoints() && ma->GetNumberOfCells() == mb->GetNumberOfCells() &&
+           ma->GetNumberOfCells() > 0 && mb->GetCellsAllocationMethod() == DynamicMesh::CellsAllocatedDynamicallyCellByCell;
+    for (unsigned long i = 0; same && i < ma->GetNumberOfPoints(); i++)
+      {
+      StaticMesh::PointType pa;
+      DynamicMesh::PointType pb;
+      same = ma->GetPoint(i, &pa) && mb->GetPoint(i, &pb);
+      for (int k = 0; same && k < 3; k++) same = pa[k] == pb[k];
+      }
+    for (unsigned long c = 0; same && c < ma->GetNumberOfCells(); c++)
+      {
+      StaticMesh::CellAutoPointer ca;
+      DynamicMesh::CellAutoPointer cb;
+      same = ma->GetCell(c, ca) && mb->GetCell(c, cb) && ca->GetNumberOfPoints() == cb->GetNumberOfPoints();
+      for (unsigned int k = 0; same && k < ca->GetNumberOfPoints(); k++) same = ca->PointIdsBegin()[k] == cb->PointIdsBegin()[k];
+      }
+    std::cout << "dynamic-traits " << (tri ? "triangles " : "quads ") << mb->GetNumberOfPoints() << " " << mb->GetNumberOfCells()
+              << (same ? " same" : " DIFFERENT") << std::endl;
+    }
+  return same;
+}
+
 int main()
 {
   try
     {
     bool ok = true;
     ok &= mesh_outlives_the_filter();
+    ok &= dynamic_traits_mesh_equals_static();
     unsigned long p[9], c[9];
     ok &= run<unsigned char>("uchar", false, p[0], c[0]);
     ok &= run<short>("short", false, p[1], c[1]);

@@ -1,4 +1,4 @@
-// The bulk fill of the output mesh (itkCuberilleImageToMeshFilter.txx: CellSlab + BulkFillCells, what replaces the reference's
+// The bulk fill of the output mesh (itkCuberilleImageToMeshFilter.txx: CellSlab + the bulk FillCells, what replaces the reference's
 // one-heap-cell-per-face loop, txx:309-329) without a GPU, so that it can run under AddressSanitizer / UBSan on any host:
 // cells in one slab that the mesh carries in its MetaDataDictionary, CellsAllocatedAsStaticArray.
 //   fill -> read back -> fill the same mesh again (the old slab must go) -> Initialize() -> a mesh that outlives every
@@ -21,7 +21,7 @@ template <class TCell, unsigned int K> static bool fill_and_check(MeshType *mesh
 {
   std::vector<uint64_t> ids(static_cast<size_t>(n) * K);
   for (size_t i = 0; i < ids.size(); i++) ids[i] = (i * 2654435761ull + salt) % 1000003ull;
-  itk::cuberille_detail::BulkFillCells<MeshType, TCell, K>(mesh, n ? &ids[0] : 0, n);
+  itk::cuberille_detail::FillCells<MeshType, TCell, K>(mesh, n ? &ids[0] : 0, n, itk::cuberille_detail::FillTag<true>());
   if (mesh->GetNumberOfCells() != n) return false;
   if (mesh->GetCellsAllocationMethod() != MeshType::CellsAllocatedAsStaticArray) return false;
   for (uint64_t c = 0; c < n; c++)
