@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 10
+#define CUBERILLE_ABI_VERSION 11
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -323,6 +323,11 @@ int cuberille_mesh_download(cuberille_ctx *ctx, float *points, uint64_t *cells);
  * destination of cuberille_mesh_download does.  Repeated calls for the same mesh return the same pointers without
  * copying again.  Either pointer argument may be null. */
 int cuberille_mesh_host(cuberille_ctx *ctx, float **points, uint64_t **cells);
+/* Gives the host memory behind cuberille_mesh_host back to the system (about 1.125 times the flat mesh, otherwise kept for the
+ * context's lifetime: a caller that has copied its mesh out -- the drop-in filter, once its itk::Mesh is filled and
+ * SetReleaseHostMeshAfterFill(true) was asked for -- and extracts rarely).  The pointers handed out become invalid; the mesh
+ * on the device stays, the next cuberille_mesh_host maps fresh memory.  (ABI 11.) */
+int cuberille_release_host_mesh(cuberille_ctx *ctx);
 
 /* Flat-mesh file output (replaces the itk::Mesh fill + itk::VTKPolyDataWriter pass of
  * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA in

@@ -1645,6 +1645,14 @@ int cuberille_mesh_host(cuberille_ctx *c, float **points, uint64_t **cells) {
   return CUBERILLE_OK;
 }
 
+int cuberille_release_host_mesh(cuberille_ctx *c) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  c->hostPoints.release();
+  c->hostCells.release();
+  c->hostMeshValid = false;
+  return CUBERILLE_OK;
+}
+
 int cuberille_mesh_write_vtk(cuberille_ctx *c, const char *path, int n_threads) {
   if (!c || !path) return CUBERILLE_ERR_ARGUMENT;
   if (!c->haveMesh) return fail(c, CUBERILLE_ERR_STATE, "no mesh: call cuberille_extract_* or cuberille_emit first");

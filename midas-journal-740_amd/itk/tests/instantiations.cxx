@@ -253,8 +253,13 @@ static bool dynamic_traits_mesh_equals_static()
   bool same = true;
   for (int tri = 0; tri < 2 && same; tri++)
     {
+    // (second round: the filters set their GPU context up inside the first Update() instead of in the constructor, and the
+    //  static one gives the context's host copy of the mesh back as soon as its itk::Mesh is filled -- same meshes)
+    StaticFilter::SetEagerDeviceSetup(tri == 0);
     StaticFilter::Pointer a = StaticFilter::New();
     DynamicFilter::Pointer b = DynamicFilter::New();
+    StaticFilter::SetEagerDeviceSetup(true);
+    a->SetReleaseHostMeshAfterFill(tri != 0);
     a->SetInput(image); b->SetInput(image);
     a->SetIsoSurfaceValue(100); b->SetIsoSurfaceValue(100);
     a->SetGenerateTriangleFaces(tri != 0); b->SetGenerateTriangleFaces(tri != 0);

@@ -412,6 +412,13 @@ def test_warm_up_and_host_mesh(pkg, oracle, volumes):
             assert_same_mesh(ex.download(), ref)
         ex.warm_up(pkg.make_desc(np.float32, (64, 64, 64)))        # between extractions: only reserves
         assert_same_mesh(ex.mesh_host(), ref)
+        # cuberille_release_host_mesh (ABI 11): the host copy goes back to the system, the mesh on the device stays -- the
+        # next cuberille_mesh_host maps fresh memory and copies again
+        ex.release_host_mesh()
+        assert_same_mesh(ex.mesh_host(), ref)
+        ex.release_host_mesh()
+        ex.release_host_mesh()
+        assert_same_mesh(ex.download(), ref)
     finally:
         ex.close()
     # the Python mirror of the filter warms up the same way (constructor, SetInput) and gives the oracle's mesh
