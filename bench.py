@@ -66,7 +66,7 @@ WORKLOADS = {
 # the rocprofv3 PMC summary (profiles/collect.sh) of exactly the configuration a line reports: workload, edge -> file
 # (file, scale, note): configs[4]'s counters are taken on a 2048 x 2048 x 256 slab of the same field -- rocprofv3's counter passes
 # die on the 8.6 GB volume -- and scaled by the slice ratio: every pass kernel's traffic is proportional to the slices it sweeps
-PMC_FILES = {("marschner_lobb", 1024): ("r4_pmc_hbm.csv", 1.0, None), ("sphere", 512): ("r4_config3_sphere512_pmc_hbm.csv", 1.0, None),
+PMC_FILES = {("marschner_lobb", 1024): ("r5_pmc_hbm.csv", 1.0, None), ("sphere", 512): ("r5_config3_sphere512_pmc_hbm.csv", 1.0, None),
              ("noise", 2048): ("r5_config5_slab2048x2048x256_pmc_hbm.csv", 8.0,
                                "counted on a 2048 x 2048 x 256 slab of the same field (the counter passes do not survive the "
                                "8.6 GB volume), scaled by 2048 / 256")}
