@@ -45,6 +45,8 @@ def _field(shape, dtype, seed=5):
     (np.int64, (100, 600, 600), 0), (np.uint64, (100, 600, 600), 1),
     # slices far shorter than a span's rows (65 slices per span: the occupancy of a word takes the division)
     (np.uint8, (70000, 3, 1300), 5),
+    # rows of ONE word (17 voxels) and of two (65): every word is a row's first and, or, last
+    (np.uint8, (4096, 4096, 17), 1), (np.float32, (1024, 1024, 65), 0),
     # whole-word rows behind a pointer that is not 16-byte aligned take the same kernel
     (np.float32, (257, 512, 512), 1), (np.uint8, (1025, 512, 512), 7)])
 def test_ragged_span_sweep_every_pixel_type(pkg, extractor, dtype, shape, skew):
@@ -120,7 +122,13 @@ def test_ragged_1000_wide_volume_matches_oracle(pkg, oracle, extractor):
     assert int(res.n_points) == len(ref.points) > 1000000
     assert_same_mesh(mesh, ref)
     assert int(res.proj_iterations) == ref.info["proj_iterations"]
+    # the same volume from HOST memory: above a GiB the upload is chunked (32 MiB = 8 slices at a time, each chunk swept by
+    # k_classify_span_rows while the next one crosses the link) -- the same mesh
+    host = vol.cpu().numpy()
     del vol
+    res = extractor.extract_host(pkg.Volume(host), prm)
+    assert int(res.proj_iterations) == ref.info["proj_iterations"]
+    assert_same_mesh(extractor.download(), ref)
 
 
 # ---- moved here from test_gpu_parity.py in round 5's split: the sweep at smaller sizes and for whole-word rows -----------
