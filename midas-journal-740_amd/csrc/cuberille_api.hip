@@ -818,7 +818,9 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
     Tuning tn = c->tune;
     // (long walks refill at 32 idle lanes: 1.161-1.166 ms against 1.178-1.192 at 16 on the headline field, three boxes, round 5;
     //  24 and 40 are no better, 48 loses 8 %)
-    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : 32;
+    // (... and at 24 below 8 M vertices: 512^3 Marschner-Lobb 0.387 against 0.398 / 0.403 ms at 16 / 32, 768^3 0.702 against
+    //  0.717 / 0.718)
+    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : (nV >= 8000000ull ? 32 : 24);
     if (c->voxelHaloEvent) {                 // the first reader of the halo's voxels
       HIP_TRY(c, hipStreamWaitEvent(s, c->voxelHaloEvent, 0));
       c->voxelHaloEvent = nullptr;
