@@ -1061,8 +1061,9 @@ __device__ __forceinline__ u64 wave_inclusive_sum2(u64 v) {     // two independe
 // FOLD_MAX_BLOCKS blocks -- every volume the reference ships, where an extraction's time is its number of launches: blob0 0.117
 // -> 0.109 ms, nucleon 0.174 -> 0.168, silicium 0.192 -> 0.188 wall.  Measured beyond that too, round 5: at 1024 blocks, all
 // resident at once (512^3), the ticket's return and the tail in ONE workgroup cost 4 us MORE than the second launch -- pass
-// 0.1214 against 0.1171 ms, profiles/microbench/r5_sphere512_{fold,nofold}.json -- and with several rounds of blocks a
-// lingering block per round costs more still (round 2): k_block_scan stays there).
+// 0.1214 against 0.1171 ms, profiles/microbench/r5_sphere512_{fold,nofold}.json; the LDS-tiled form of that size with the tail's
+// loads all issued at once: 0.1249 against 0.1150 -- and with several rounds of blocks a lingering block per round costs more
+// still (round 2): k_block_scan stays there).
 // Hand-off (MI355X guide, inter-workgroup visibility): every block's wave 0 stores its total (and g0pre) write-through
 // (agent-scope atomic stores = sc1), waits for them (vmcnt(0)), then adds to the ticket; the block whose add returns
 // nblk - 1 acquires at agent scope and reads every total with agent-scope loads.  The err and nVertexWords words are only ever
