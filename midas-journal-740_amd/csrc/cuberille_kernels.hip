@@ -2536,9 +2536,18 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   // every XCD one contiguous eighth of the vertex list so that chunks whose cells overlap (adjacent
   // rows and slices) meet in the same L2.  Placement only affects speed, never results.
   u64 lb = blockIdx.x;
-  if (xcdRemap) {
+  if (xcdRemap == 1) {
     const u64 nb = gridDim.x, per = nb / 8, rem = nb % 8, x = lb % 8, j = lb / 8;
     lb = x * per + (x < rem ? x : rem) + j;
+  } else if (xcdRemap > 1) {
+    // runs of G consecutive workgroups' worth of batches on one XCD -- workgroup b sits on XCD b % 8 -- so that batches whose
+    // cells overlap (neighbouring rows) meet in one L2; super-groups of 8 G workgroups, the grid's ragged end left as it is
+    // (launch_project: short walks)
+    const u64 G = (u64)xcdRemap, nb = gridDim.x, sg = lb / (8 * G);
+    if ((sg + 1) * 8 * G <= nb) {
+      const u64 in = lb - sg * 8 * G, x = in % 8, j = in / 8;
+      lb = sg * 8 * G + x * G + j;
+    }
   }
   // Work assignment: the vertex list is cut into batches of `chunk` (a power of two) vertices; wave w
   // takes batches w, w+NW, w+2NW, ... (NW = waves in the grid).  With the grid resident, all waves
@@ -3463,10 +3472,20 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
     typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
     const unsigned blocks = grid_for(nwaves * 64, 256, 0);
-    // (giving each XCD a contiguous eighth of the vertex list was measured 1.6x slower: proj_xcd stays a switch)
+    // (giving each XCD a contiguous EIGHTH of the vertex list was measured 1.6x slower, round 1: proj_xcd = 1.  Round 5, after
+    //  the counters had shown the dense-field walk to be bound by L1 / L2 misses of its gathers: RUNS of G consecutive
+    //  workgroups on one XCD (proj_xcd = G > 1) -- 2048^3 noise 12.33 -> 10.9 ms at G = 64 (11.0 at 32 and 128), 1024^3 1.395 ->
+    //  1.358 at 16 (1.363 / 1.381 at 32 / 64), and the row-width effect itself goes: 8192 x 512 x 256 77.2 -> 49.5 ps per vertex,
+    //  the figure of 512-voxel rows.  Short walks take G = workgroups / 512 within 16 .. 64; on the long walks of a sheet the
+    //  same switch is within the noise of a box, and once worse (1000^3 sphere, G = 16): off there.)
+    int xcd = tn.proj_xcd;
+    if (xcd == 0 && shortWalks && blocks >= 16 * 512) {
+      const unsigned gq = blocks / 512;
+      xcd = (int)(gq < 16 ? 16 : gq > 64 ? 64 : gq);
+    } else if (xcd < 0) xcd = 0;
 #define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
     hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
-                       w.points, nPoints, nGhost, chunk, tn.proj_refill, tn.proj_xcd, tn.proj_literal, w.totals, w.escList,  \
+                       w.points, nPoints, nGhost, chunk, tn.proj_refill, xcd, tn.proj_literal, w.totals, w.escList,  \
                        w.escCap, dyn)
     if (mode == 1) CUBERILLE_LAUNCH_PROJECT(1);
     else if (mode == 2) CUBERILLE_LAUNCH_PROJECT(2);
