@@ -3476,12 +3476,16 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     //  the counters had shown the dense-field walk to be bound by L1 / L2 misses of its gathers: RUNS of G consecutive
     //  workgroups on one XCD (proj_xcd = G > 1) -- 2048^3 noise 12.33 -> 10.9 ms at G = 64 (11.0 at 32 and 128), 1024^3 1.395 ->
     //  1.358 at 16 (1.363 / 1.381 at 32 / 64), and the row-width effect itself goes: 8192 x 512 x 256 77.2 -> 49.5 ps per vertex,
-    //  the figure of 512-voxel rows.  Short walks take G = workgroups / 512 within 16 .. 64; on the long walks of a sheet the
-    //  same switch is within the noise of a box, and once worse (1000^3 sphere, G = 16): off there.)
+    //  the figure of 512-voxel rows.  Short walks take G = workgroups / 512 within 16 .. 64.  Long walks, interleaved A/B:
+    //  G = 32 is worth 4.4 % on 2048^3 Marschner-Lobb (4.25 -> 4.06 ms), 9 % on a 1000^3 sphere (0.513 -> 0.466), 5 % on a 768^3
+    //  one, 2 % on 512^3 Marschner-Lobb, and nothing either way on the headline's 1024^3 sheet (1.164-1.184 against 1.165-1.184);
+    //  G = 8 .. 16 can lose (1000^3 sphere 0.60-0.62 ms) and G = 64 costs the headline 2 %: 32 from 1024 workgroups on.)
     int xcd = tn.proj_xcd;
     if (xcd == 0 && shortWalks && blocks >= 16 * 512) {
       const unsigned gq = blocks / 512;
       xcd = (int)(gq < 16 ? 16 : gq > 64 ? 64 : gq);
+    } else if (xcd == 0 && !shortWalks && blocks >= 1024) {
+      xcd = 32;
     } else if (xcd < 0) xcd = 0;
 #define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
     hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
