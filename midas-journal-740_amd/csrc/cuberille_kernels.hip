@@ -3479,12 +3479,14 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     //  the figure of 512-voxel rows.  Short walks take G = workgroups / 512 within 16 .. 64.  Long walks, interleaved A/B:
     //  G = 32 is worth 4.4 % on 2048^3 Marschner-Lobb (4.25 -> 4.06 ms), 9 % on a 1000^3 sphere (0.513 -> 0.466), 5 % on a 768^3
     //  one, 2 % on 512^3 Marschner-Lobb, and nothing either way on the headline's 1024^3 sheet (1.164-1.184 against 1.165-1.184);
-    //  G = 8 .. 16 can lose (1000^3 sphere 0.60-0.62 ms) and G = 64 costs the headline 2 %: 32 from 1024 workgroups on.)
+    //  G = 8 .. 16 can lose (1000^3 sphere 0.60-0.62 ms) and G = 64 costs the headline 2 %.  With 32 as the rule the headline's
+    //  walk read 1.187-1.191 ms in three stage-timed lines and 1.215 under rocprofv3 against 1.162-1.165 and 1.199 before:
+    //  launches of 2304 .. 8191 workgroups (768^3 and 1024^3 Marschner-Lobb: nothing and -1.5 %) keep the plain order.)
     int xcd = tn.proj_xcd;
     if (xcd == 0 && shortWalks && blocks >= 16 * 512) {
       const unsigned gq = blocks / 512;
       xcd = (int)(gq < 16 ? 16 : gq > 64 ? 64 : gq);
-    } else if (xcd == 0 && !shortWalks && blocks >= 1024) {
+    } else if (xcd == 0 && !shortWalks && blocks >= 1024 && (blocks < 2304 || blocks >= 8192)) {
       xcd = 32;
     } else if (xcd < 0) xcd = 0;
 #define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
