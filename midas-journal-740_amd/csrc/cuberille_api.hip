@@ -820,7 +820,8 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
     //  24 and 40 are no better, 48 loses 8 %)
     // (... and at 24 below 8 M vertices: 512^3 Marschner-Lobb 0.387 against 0.398 / 0.403 ms at 16 / 32, 768^3 0.702 against
     //  0.717 / 0.718)
-    if (tn.proj_refill <= 0) tn.proj_refill = c->haveHistory && c->histShortWalks ? 64 : (nV >= 8000000ull ? 32 : 24);
+    if (tn.proj_short < 0) tn.proj_short = c->haveHistory && c->histShortWalks ? 1 : 0;
+    if (tn.proj_refill <= 0) tn.proj_refill = tn.proj_short ? 64 : (nV >= 8000000ull ? 32 : 24);
     if (c->voxelHaloEvent) {                 // the first reader of the halo's voxels
       HIP_TRY(c, hipStreamWaitEvent(s, c->voxelHaloEvent, 0));
       c->voxelHaloEvent = nullptr;
@@ -1491,7 +1492,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split) OPT(count_no_fold)
+  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split) OPT(count_no_fold) OPT(proj_short)
 #undef OPT
   return false;
 }

@@ -141,6 +141,7 @@ struct Tuning {
   // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass
   // (proj_waves 0: 16 384, or 65 536 waves dealing batches of 64 where walks are short -- see launch_project)
   int proj_chunk = 0, proj_waves = 0, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
+  int proj_short = -1;        // the launch shapes of SHORT walks (1) or of long ones (0); -1: by the previous extraction's passes per vertex
   int count_no_fold = 0;      // 1: the block scan always as a launch of its own (A/B of the scan folded into small count launches)
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)
 };

@@ -3456,7 +3456,7 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   //  of rounds 1-4 at the headline's 11.1 M vertices (12 288 / 16 384 / 20 480 / 24 576 waves: 1.157 / 1.144 / 1.193 / 1.170 ms) --
   //  512^3 (2.8 M vertices) 4096 waves 0.388 against 0.439 ms, 768^3 12 288 waves 0.717 against 0.739, 2048^3 (44.8 M)
   //  65 536 waves 4.14 against 4.30.  Below 4096 waves' worth of vertices the launch shapes of rounds 3-4 stand.)
-  const bool shortWalks = tn.proj_refill >= 64;
+  const bool shortWalks = tn.proj_short >= 0 ? tn.proj_short != 0 : tn.proj_refill >= 64;
   const u64 perWave = shortWalks ? 448 : 680;
   u64 autoWaves = 16384;
   // (... in whole rounds of the 4096 waves the chip holds at 4 per SIMD: 4435 waves for the 3.0 M vertices of a 1000^3 sphere are

@@ -149,7 +149,7 @@ def test_anisotropic_geometry(pkg, oracle, extractor, volumes):
 
 
 @pytest.mark.parametrize("options", [("no_cmap",), ("no_heads",), ("no_vqueue",), ("no_vqueue", "no_heads"), ("count_no_fold",),
-                                     ("proj_xcd=2", "proj_waves=64"), ("proj_xcd=1", "proj_waves=64"), ("proj_xcd=3", "proj_waves=100", "proj_refill=64"),
+                                     ("proj_xcd=2", "proj_waves=64"), ("proj_xcd=1", "proj_waves=64"), ("proj_xcd=3", "proj_waves=100", "proj_refill=64"), ("proj_short=1", "proj_refill=16"),
                                      ("no_cmap", "no_heads", "no_vqueue"), ("classify_variant",),
                                      ("points_no_split", "proj_chunk=128"), ("cmap_linear",), ("proj_refill=64",), ("proj_refill=3", "proj_chunk=256"),
                                      ("points_split=2", "classify_keep_tail"), ("points_split=4", "proj_chunk64_below=1")])
