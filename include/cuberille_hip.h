@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 11
+#define CUBERILLE_ABI_VERSION 12
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -328,6 +328,21 @@ int cuberille_mesh_host(cuberille_ctx *ctx, float **points, uint64_t **cells);
  * SetReleaseHostMeshAfterFill(true) was asked for -- and extracts rarely).  The pointers handed out become invalid; the mesh
  * on the device stays, the next cuberille_mesh_host maps fresh memory.  (ABI 11.) */
 int cuberille_release_host_mesh(cuberille_ctx *ctx);
+
+/* Quirk Q3 of the reference, on request.  ComputeGradientImage() (itkCuberilleImageToMeshFilter.txx:478-498) builds the
+ * gradient image and its interpolator only while m_GradientInterpolator is null (txx:484) and nothing ever resets it: from
+ * the second Update() of a filter object on, whatever the input, the walk of txx:439-474 follows the gradient -- and maps its
+ * points through the geometry -- of the image the FIRST projecting Update() saw.  This library evaluates the current
+ * volume's gradient by default.  With hold != 0 a context behaves like the reference's filter
+ * object: its next extraction with project_vertices on (a whole volume: slabs are refused) also materialises that volume's
+ * float gradient image in device memory (12 bytes per voxel) and every later extraction on the context, of any size,
+ * geometry or pixel type, walks along it -- results then equal a second Update() of the reference bit for bit (the
+ * oracle's cuberille_oracle_run_after).  Offered with CUBERILLE_GRADIENT_CENTRAL and every projection_variant; such
+ * extractions take the plain one-lane-per-vertex walk, not the refilling one.  hold == 0 drops the image and returns to the
+ * default.  Not to be called between cuberille_step_begin and cuberille_step_end.  (ABI 12.) */
+int cuberille_hold_gradient(cuberille_ctx *ctx, int hold);
+/* 1 when the context holds a gradient image (dims, if not null, receives its size in voxels; zeros otherwise), else 0. */
+int cuberille_gradient_held(cuberille_ctx *ctx, int64_t dims[3]);
 
 /* Flat-mesh file output (replaces the itk::Mesh fill + itk::VTKPolyDataWriter pass of
  * Testing/CuberilleTest01.cxx:161-187 for callers that keep the flat buffers): legacy-ASCII VTK POLYDATA in

@@ -28,9 +28,9 @@ EXPORTS = [
     "cuberille_extract_stream", "cuberille_emit_points", "cuberille_slice_bits_device", "cuberille_recount", "cuberille_alias_plane_device", "cuberille_set_alias_plane",
     "cuberille_minimum_halo", "cuberille_escaped_count", "cuberille_reproject_escaped", "cuberille_step_begin", "cuberille_step_end",
     "cuberille_slice_counts", "cuberille_failed_row", "cuberille_warm_up", "cuberille_mesh_host", "cuberille_step_classify", "cuberille_step_count",
-    "cuberille_release_host_mesh",
+    "cuberille_release_host_mesh", "cuberille_hold_gradient", "cuberille_gradient_held",
 ]
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ImageDesc(C.Structure):
@@ -126,6 +126,8 @@ def lib():
     L.cuberille_mesh_download.argtypes = [vp, vp, vp]
     L.cuberille_mesh_host.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cuberille_release_host_mesh.argtypes = [vp]
+    L.cuberille_hold_gradient.argtypes = [vp, C.c_int]
+    L.cuberille_gradient_held.argtypes = [vp, C.POINTER(C.c_int64)]
     L.cuberille_debug_bits.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_slice_occupancy.argtypes = [vp, vp, C.c_size_t]
     L.cuberille_write_vtk_buffers.argtypes = [C.c_char_p, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int]

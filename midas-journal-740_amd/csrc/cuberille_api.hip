@@ -103,6 +103,9 @@ struct cuberille_ctx {
   std::string err;
   DevBuf voxOwn, bits, flatBits, occ, prefix, segPre, blockTot, blockBase, points, cells, cmap, headV, headQ, vqueue, escList;
   DevBuf gradImg, rgA, rgB, rgScratch;   // gradient_variant 1: the gradient image and what its passes go through
+  DevBuf heldGrad;                       // cuberille_hold_gradient: the float gradient image of the first projecting extraction
+  HeldGradient held{};                   // ... with its geometry (img == null: none yet); what every later walk follows
+  bool holdGradient = false;             // ... asked for
   HostBuf hostPoints, hostCells;         // cuberille_mesh_host: the last mesh in host memory of the context's own
   bool hostMeshValid = false;            // ... holds the mesh of the last emit
   Totals *hostTotals = nullptr;          // pinned
@@ -217,6 +220,8 @@ int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox,
     return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown projection variant");
   if (prm->gradient_variant < CUBERILLE_GRADIENT_CENTRAL || prm->gradient_variant > CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN)
     return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown gradient variant");
+  if (prm->gradient_variant == CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN && prm->project_vertices && c->holdGradient)
+    return fail(c, CUBERILLE_ERR_ARGUMENT, "cuberille_hold_gradient holds the central-difference gradient image the reference ships: not offered with the recursive-Gaussian one");
   if (prm->gradient_variant == CUBERILLE_GRADIENT_RECURSIVE_GAUSSIAN && prm->project_vertices)
     for (int i = 0; i < 3; i++)
       if (img->dims[i] < 4)   // (ITK's recursive filter throws for shorter lines)
@@ -289,7 +294,7 @@ void cuberille_destroy(cuberille_ctx *c) {
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   DevBuf *bufs[] = {&c->voxOwn, &c->bits, &c->flatBits, &c->occ, &c->prefix, &c->segPre, &c->blockTot, &c->blockBase,
                     &c->points, &c->cells, &c->cmap, &c->headV, &c->headQ, &c->vqueue, &c->escList,
-                    &c->gradImg, &c->rgA, &c->rgB, &c->rgScratch};
+                    &c->gradImg, &c->rgA, &c->rgB, &c->rgScratch, &c->heldGrad};
   for (DevBuf *b : bufs) b->release();
   c->hostPoints.release();
   c->hostCells.release();
@@ -450,6 +455,8 @@ int count_prepare(cuberille_ctx *c, const cuberille_image_desc *img, const void 
     // (a THIN_HALO slab promises the topology's slices only; walks that want more are put aside, not clamped)
     if (p.project && p.gradVariant != CUBERILLE_GRADIENT_CENTRAL)
       return fail(c, CUBERILLE_ERR_ARGUMENT, "the recursive-Gaussian gradient filters whole lines of the volume: not offered on slabs");
+    if (p.project && c->holdGradient)
+      return fail(c, CUBERILLE_ERR_ARGUMENT, "a held gradient image (cuberille_hold_gradient) belongs to a whole volume: not offered on slabs");
     const bool thin = (slab->flags & CUBERILLE_SLAB_THIN_HALO) != 0;
     if (thin && p.project && p.variant != CUBERILLE_PROJECT_DEFAULT)
       return fail(c, CUBERILLE_ERR_ARGUMENT, "a THIN_HALO slab is only offered with the default projection branch");
@@ -826,7 +833,18 @@ int emit_points_phase(cuberille_ctx *c, bool dyn = false, u64 coverV = 0, u64 co
       HIP_TRY(c, hipStreamWaitEvent(s, c->voxelHaloEvent, 0));
       c->voxelHaloEvent = nullptr;
     }
+    w.held = c->holdGradient && c->held.img ? &c->held : nullptr;
     HIP_TRY(c, launch_project(c->pixel_type, w, c->g, c->geo, c->prm, nV, nGhost, tn, c->thinHalo ? 1 : 0, dyn ? 1 : 0, s));
+    if (c->holdGradient && !c->held.img) {
+      // quirk Q3 on request: this is the context's first projecting extraction -- ComputeGradientImage() of txx:478-498
+      // runs (the walk above evaluated the same taps on the fly) and its image stays for every extraction to come
+      const size_t nvox = (size_t)c->g.nx * c->g.ny * c->g.nzb;
+      HIP_TRY(c, c->heldGrad.reserve(nvox * 3 * sizeof(float)));
+      HIP_TRY(c, launch_gradient_image(c->pixel_type, w, c->g, c->geo, (float *)c->heldGrad.p, s));
+      c->held.img = (const float *)c->heldGrad.p;
+      c->held.geo = c->geo;
+      c->held.n[0] = c->g.nx; c->held.n[1] = c->g.ny; c->held.n[2] = c->g.nzb;
+    }
   }
   if (c->stagesTimed) HIP_TRY(c, hipEventRecord(c->ev[6], s));
   c->pointsEmitted = true;
@@ -1012,7 +1030,8 @@ int step_launch(cuberille_ctx *c, const void **dev_row, size_t *row_bytes) {
   // blind launches need: the sizes of a previous extraction on this context, the default projection branch and every
   // scratch table (the vertex-word queue is set up by count_prepare; the others are checked below)
   const bool blind = c->haveHistory && c->w.vqueue && !c->tune.no_cmap && !c->tune.no_heads && c->tune.points_variant == 3 &&
-                     (!c->prm.project || (c->prm.variant == CUBERILLE_PROJECT_DEFAULT && c->prm.gradVariant == 0)) && c->histV + c->histV / 4 < 0xfffff000ULL;
+                     (!c->prm.project || (c->prm.variant == CUBERILLE_PROJECT_DEFAULT && c->prm.gradVariant == 0 && !c->holdGradient)) &&
+                     c->histV + c->histV / 4 < 0xfffff000ULL;
   if (blind) {
     Gate gate{};
     gate.on = 1;
@@ -1646,6 +1665,25 @@ int cuberille_mesh_host(cuberille_ctx *c, float **points, uint64_t **cells) {
   if (points) *points = (float *)c->hostPoints.p;
   if (cells) *cells = (uint64_t *)c->hostCells.p;
   return CUBERILLE_OK;
+}
+
+int cuberille_hold_gradient(cuberille_ctx *c, int hold) {
+  if (!c) return CUBERILLE_ERR_ARGUMENT;
+  if (c->stepMode != 0) return fail(c, CUBERILLE_ERR_STATE, "a step is open on this context");
+  c->holdGradient = hold != 0;
+  if (!hold && c->held.img) {
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));     // (a walk may still be reading it)
+    c->heldGrad.release();
+    c->held = HeldGradient{};
+  }
+  return CUBERILLE_OK;
+}
+
+int cuberille_gradient_held(cuberille_ctx *c, int64_t dims[3]) {
+  if (!c) return 0;
+  if (dims) for (int i = 0; i < 3; i++) dims[i] = c->held.img ? c->held.n[i] : 0;
+  return c->held.img ? 1 : 0;
 }
 
 int cuberille_release_host_mesh(cuberille_ctx *c) {

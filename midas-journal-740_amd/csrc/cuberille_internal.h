@@ -96,6 +96,15 @@ constexpr unsigned ESCAPE_LIST_CAP = 1u << 20;   // entries of the THIN_HALO esc
 constexpr int COUNT_LG = 11;
 constexpr int COUNT_WB = 1 << COUNT_LG;
 
+// Quirk Q3 reproduced on request (cuberille_hold_gradient): the float gradient image of the volume of a context's FIRST
+// projecting extraction and that volume's geometry -- what the reference's cached gradient interpolator goes on
+// evaluating for the life of the filter object (txx:484).  img == null: none held, the walk evaluates the current volume.
+struct HeldGradient {
+  const float *img;    // CovariantVector<float,3> per pixel, x fastest
+  Geo geo;
+  int n[3];
+};
+
 struct Workspace {     // device pointers valid for one count/emit pair
   const void *vox;
   u64 *bits;
@@ -116,6 +125,7 @@ struct Workspace {     // device pointers valid for one count/emit pair
   double *rgScratch;
   u32 *escList;        // THIN_HALO: indices (in this rank's point buffer) of the vertices whose walk left the buffer
   u32 escCap;
+  const HeldGradient *held;   // (host pointer) the held gradient image the walk follows instead of the volume's own, or null
 };
 
 // Development switches, set per context through cuberille_debug_set_option (never read from the environment).
@@ -181,6 +191,7 @@ hipError_t launch_alias_plane(const Workspace &w, const Grid &g, int zLocal, u64
                               hipStream_t s);
 hipError_t launch_recursive_gaussian(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, const double coef[3][2][20],
                                      hipStream_t s);
+hipError_t launch_gradient_image(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, float *out, hipStream_t s);
 hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo,
                           const Params &p, u64 nPoints, u64 nGhost, const Tuning &t, int mode, int dyn, hipStream_t s);
 

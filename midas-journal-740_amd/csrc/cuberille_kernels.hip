@@ -2765,6 +2765,8 @@ struct VariantCtx {
   int n[3];
   double iso;
   const double *gimg;   // the recursive-Gaussian variant's gradient image (CovariantVector<double,3> per pixel), or null
+  HeldGradient held;    // quirk Q3 on request: the gradient image (and geometry) of an earlier volume, or img == null
+  bool heldUnitP2I;
 };
 
 // I7 + I8: the interpolated gradient at `vertex`, normalised (txx:356-357, 408-409, 451-452), as the double vector the
@@ -2800,19 +2802,39 @@ __device__ void variant_normal(const VariantCtx<T> &x, const float vertex[3], do
     return;
   }
   float normal[3];
-  float G[8][3];
-  typename SiteValue<T>::type Vd[8];
-  gather_cell<T, true>(x.s, x.geo, x.dirIdentity, c, G, Vd);
   double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+  if (x.held.img) {
+    // the cached interpolator of txx:484: the point goes through the HELD image's geometry, the eight sites come from its
+    // gradient image (I7), clamped to ITS extent (I5)
+    Cell8 h;
+    make_cell(x.held.geo, x.heldUnitP2I, x.held.n, p, h);
 #pragma unroll
-  for (unsigned counter = 0; counter < 8; counter++) {
-    double overlap = 1.0;
+    for (unsigned counter = 0; counter < 8; counter++) {
+      double overlap = 1.0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
-    if (overlap != 0.0 && total != 1.0) {
+      for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? h.d[k] : (1.0 - h.d[k]);
+      if (overlap != 0.0 && total != 1.0) {
+        const int sx = (counter & 1) ? h.hi[0] : h.lo[0], sy = (counter & 2) ? h.hi[1] : h.lo[1], sz = (counter & 4) ? h.hi[2] : h.lo[2];
+        const float *gp = x.held.img + 3 * (((size_t)sz * x.held.n[1] + sy) * x.held.n[0] + sx);
 #pragma unroll
-      for (int k = 0; k < 3; k++) acc[k] += overlap * (double)G[counter][k];
-      total += overlap;
+        for (int k = 0; k < 3; k++) acc[k] += overlap * (double)gp[k];
+        total += overlap;
+      }
+    }
+  } else {
+    float G[8][3];
+    typename SiteValue<T>::type Vd[8];
+    gather_cell<T, true>(x.s, x.geo, x.dirIdentity, c, G, Vd);
+#pragma unroll
+    for (unsigned counter = 0; counter < 8; counter++) {
+      double overlap = 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) overlap *= (counter & (1u << k)) ? c.d[k] : (1.0 - c.d[k]);
+      if (overlap != 0.0 && total != 1.0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] += overlap * (double)G[counter][k];
+        total += overlap;
+      }
     }
   }
   double sq = 0.0;
@@ -2847,7 +2869,8 @@ __device__ double variant_value(const VariantCtx<T> &x, const float q[3]) {
 template <class T>
 __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
                                                          float *__restrict__ points, u64 nPoints, u64 nGhost,
-                                                         Totals *__restrict__ tot, const double *__restrict__ gimg) {
+                                                         Totals *__restrict__ tot, const double *__restrict__ gimg,
+                                                         HeldGradient held) {
   const int lane = threadIdx.x & 63;
   const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned passes = 0;
@@ -2863,6 +2886,9 @@ __global__ __launch_bounds__(256) void k_project_variant(const T *__restrict__ v
     x.n[0] = g.nx; x.n[1] = g.ny; x.n[2] = (int)g.gnz;
     x.iso = (double)iso_as<T>(prm.iso, prm.isoInt);
     x.gimg = gimg;
+    x.held = held;
+    x.heldUnitP2I = true;
+    for (int i = 0; i < 9; i++) x.heldUnitP2I = x.heldUnitP2I && (held.geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
     float vertex[3] = {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
     double normal[3];
     if (prm.variant == CUBERILLE_PROJECT_DEFAULT) {
@@ -3419,6 +3445,34 @@ hipError_t launch_emit_cells(const Workspace &w, const Grid &g, int triangles, i
   return hipGetLastError();
 }
 
+// The gradient image of txx:478-498 materialised (I6 at every pixel) -- only for a context asked to hold it across
+// extractions (quirk Q3, cuberille_hold_gradient); the walk of an ordinary extraction evaluates the same taps on the fly.
+template <class T>
+__global__ __launch_bounds__(256) void k_gradient_image(const T *__restrict__ vox, Grid g, Geo geo, int dirIdentity,
+                                                        float *__restrict__ out, size_t nvox) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  const int x = (int)(i % (size_t)g.nx), y = (int)((i / (size_t)g.nx) % (size_t)g.ny), z = (int)(i / ((size_t)g.nx * g.ny));
+  const Sampler<T> s{vox, g.nx, g.ny, g.nzb, 0, g.nzb};
+  float gr[3];
+  gradient_at(s, geo, dirIdentity != 0, x, y, z, (float)vox[i], gr);
+  out[3 * i] = gr[0]; out[3 * i + 1] = gr[1]; out[3 * i + 2] = gr[2];
+}
+
+hipError_t launch_gradient_image(int pixel_type, const Workspace &w, const Grid &g, const Geo &geo, float *out, hipStream_t s) {
+  const size_t nvox = (size_t)g.nx * g.ny * g.nzb;
+  if (nvox == 0) return hipSuccess;
+  if ((nvox + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+  int dirIdentity = 1;
+  for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
+  return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
+    typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+    hipLaunchKernelGGL((k_gradient_image<T>), dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, s, (const T *)w.vox, g, geo,
+                       dirIdentity, out, nvox);
+    return hipGetLastError();
+  });
+}
+
 // mode: 0 plain, 1 THIN_HALO escape detection (w.escList), 2 the escaped vertices again (nPoints = their number; `g`
 // and w.vox describe the deeper buffer).  dyn: sizes from the device totals (cuberille_step_begin); nPoints is then
 // only what the launch is sized for.
@@ -3427,11 +3481,13 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   if (nPoints == 0) return hipSuccess;
   int dirIdentity = 1;
   for (int i = 0; i < 9; i++) if (geo.dir[i] != ((i % 4 == 0) ? 1.0 : 0.0)) dirIdentity = 0;
-  if (p.variant != CUBERILLE_PROJECT_DEFAULT || p.gradVariant != 0)
+  if (p.variant != CUBERILLE_PROJECT_DEFAULT || p.gradVariant != 0 || (w.held && w.held->img))
     return by_pixel_type(pixel_type, [&](auto *tag) -> hipError_t {
       typedef typename std::remove_cv<typename std::remove_pointer<decltype(tag)>::type>::type T;
+      HeldGradient held{};
+      if (w.held && w.held->img) held = *w.held;
       hipLaunchKernelGGL((k_project_variant<T>), dim3(grid_for(nPoints, 256, 0)), dim3(256), 0, s, (const T *)w.vox, g, geo, p,
-                         dirIdentity, w.points, nPoints, nGhost, w.totals, p.gradVariant ? w.gradImg : nullptr);
+                         dirIdentity, w.points, nPoints, nGhost, w.totals, p.gradVariant ? w.gradImg : nullptr, held);
       return hipGetLastError();
     });
   // batches of 128 vertices dealt round-robin to 16384 waves (same-box A/B at 1024^3 M-L: 1.54 ms vs 1.68 ms

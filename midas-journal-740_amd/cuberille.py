@@ -344,6 +344,20 @@ class Extractor:
         """Give the host memory behind mesh_host() back to the system (views handed out before become invalid)."""
         _abi.check(self._ctx, self._lib.cuberille_release_host_mesh(self._ctx))
 
+    def hold_gradient(self, hold=True):
+        """Quirk Q3 of the reference on request (cuberille_hold_gradient; txx:484): like the reference's filter object, this
+        extractor keeps the gradient image (and geometry) of its next projecting extraction and walks every later volume
+        along it.  hold=False drops the image and returns to the default: each volume's own gradient."""
+        _abi.check(self._ctx, self._lib.cuberille_hold_gradient(self._ctx, 1 if hold else 0))
+
+    @property
+    def gradient_held(self):
+        """None, or the (nz, ny, nx) of the volume whose gradient image the extractor holds."""
+        dims = (C.c_int64 * 3)()
+        if not self._lib.cuberille_gradient_held(self._ctx, dims):
+            return None
+        return (int(dims[2]), int(dims[1]), int(dims[0]))
+
     def write_vtk(self, path, threads=0):
         """Download the last whole-volume mesh and write it as legacy-ASCII VTK POLYDATA."""
         _abi.check(self._ctx, self._lib.cuberille_mesh_write_vtk(self._ctx, os.fsencode(path), int(threads)))
@@ -448,6 +462,7 @@ class CuberilleImageToMeshFilter:
         self._q1 = True
         self._variant = PROJECT_DEFAULT           # h:22-23: both alternative branches are compiled out
         self._gradient = GRADIENT_CENTRAL         # h:21: and so is the recursive-Gaussian gradient
+        self._stale_gradient = False
         self.last_result = None
         # like the C++ drop-in: the GPU context and the code objects are set up when the filter is made, not inside the
         # first Update() (the reference's driver times one cold Update(), test:158-160); silent without a device --
@@ -555,6 +570,15 @@ class CuberilleImageToMeshFilter:
             raise ValueError("gradient variant must be 0 or 1")
         self._gradient = int(gradient)
 
+    def SetReproduceStaleGradient(self, b):
+        """Not in the reference -- its behaviour, on request (like the C++ drop-in's switch of the same name): the reference's
+        gradient interpolator is created once per filter object (txx:484), so every Update() after the first projecting
+        one walks along the FIRST input's gradient.  Default off: each input's own gradient."""
+        self._stale_gradient = bool(b)
+
+    def GetReproduceStaleGradient(self):
+        return self._stale_gradient
+
     def Update(self):
         if self._input is None:
             # the ITK pipeline throws for a missing required input (txx:33)
@@ -565,6 +589,7 @@ class CuberilleImageToMeshFilter:
             self._step = max(vol.spacing) * 0.25
         prm = make_params(self._iso, self._triangles, self._project, self._threshold, self._step, self._relax,
                           self._max_steps, self._q1, self._variant, self._gradient)
+        self._extractor.hold_gradient(self._stale_gradient)
         self.last_result = self._extractor.extract_host(vol, prm)
         self._output = self._extractor.download()
 

@@ -182,6 +182,17 @@ public:
   itkSetMacro(ReleaseHostMeshAfterFill, bool);
   itkBooleanMacro(ReleaseHostMeshAfterFill);
 
+  /** Not in the reference -- its behaviour, on request.  The reference builds its gradient image and gradient interpolator
+   *  only while the interpolator is null (txx:484) and never resets it: from the second Update() of a filter object on, the
+   *  walk follows the gradient of the image the FIRST projecting Update() saw, whatever the input is by then.  This drop-in
+   *  uses the current input's gradient; true makes the filter object behave like the reference's, update for update
+   *  (cuberille_hold_gradient: the first input's gradient image stays on the device, 12 bytes per voxel).  Default false.
+   *  Takes effect with the default LinearInterpolateImageFunction (the device walk); setting it back to false drops the
+   *  held image. */
+  itkGetMacro(ReproduceStaleGradient, bool);
+  itkSetMacro(ReproduceStaleGradient, bool);
+  itkBooleanMacro(ReproduceStaleGradient);
+
 protected:
   CuberilleImageToMeshFilter();
   ~CuberilleImageToMeshFilter();
@@ -206,6 +217,7 @@ private:
   int m_Device;
   unsigned int m_HostWalkThreads;
   bool m_ReleaseHostMeshAfterFill;
+  bool m_ReproduceStaleGradient;
   double m_LastDeviceSeconds;
   double m_LastMeshFillSeconds;
   double m_LastExtractSeconds;

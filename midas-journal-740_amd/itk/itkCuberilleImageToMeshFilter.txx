@@ -465,6 +465,7 @@ CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::CuberilleIm
   m_Device = 0;
   m_HostWalkThreads = 1;
   m_ReleaseHostMeshAfterFill = false;
+  m_ReproduceStaleGradient = false;
   m_LastDeviceSeconds = 0.0;
   m_LastMeshFillSeconds = 0.0;
   m_LastExtractSeconds = 0.0;
@@ -562,6 +563,8 @@ void CuberilleImageToMeshFilter<TInputImage, TOutputMesh, TInterpolator>::Genera
                          "offered with the default LinearInterpolateImageFunction");
 
   this->AcquireContext(true);
+  if (cuberille_hold_gradient(m_Context, (m_ReproduceStaleGradient && !hostWalk) ? 1 : 0) != CUBERILLE_OK)
+    itkExceptionMacro(<< "cuberille_hold_gradient: " << cuberille_last_error(m_Context));
   cuberille_result res;
   const double extractStart = cuberille_detail::WallSeconds();
   if (cuberille_extract_host(m_Context, &desc, image->GetBufferPointer(), &prm, &res) != CUBERILLE_OK)

@@ -6,6 +6,7 @@
 #include <iostream>
 #include <set>
 #include <utility>
+#include <vector>
 
 #include "itkImage.h"
 #include "itkMesh.h"
@@ -289,11 +290,98 @@ static bool dynamic_traits_mesh_equals_static()
   return same;
 }
 
-int main()
+// SetReproduceStaleGradient (not in the reference: its behaviour -- quirk Q3, txx:484 -- on request): a filter object that has
+// projected once goes on walking along that first input's gradient.  Self-consistency here (a fresh filter, and the same
+// filter with the switch off again, give the second input's own mesh; the stale one differs in coordinates only); with a file
+// name the stale mesh is written out and tests/test_gpu_boundary.py holds it against the oracle's run_after.
+static itk::Image<float, 3>::Pointer stale_field(int nx, int ny, int nz, double cx, double radius)
+{
+  typedef itk::Image<float, 3> ImageType;
+  ImageType::Pointer image = ImageType::New();
+  ImageType::RegionType region;
+  ImageType::IndexType start;
+  ImageType::SizeType size;
+  start.Fill(0);
+  size[0] = nx; size[1] = ny; size[2] = nz;
+  region.SetIndex(start);
+  region.SetSize(size);
+  image->SetRegions(region);
+  image->Allocate();
+  for (int z = 0; z < nz; z++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++)
+        {
+        ImageType::IndexType idx;
+        idx[0] = x; idx[1] = y; idx[2] = z;
+        const double r = std::sqrt((x - cx) * (x - cx) + (y - 10.25) * (y - 10.25) + (z - 9.5) * (z - 9.5));
+        image->SetPixel(idx, static_cast<float>(radius - r + 0.03125 * ((x * 7 + y * 13 + z * 5) % 11)));
+        }
+  return image;
+}
+
+template <class TMesh> static std::vector<float> flat_points(const TMesh *m)
+{
+  std::vector<float> out;
+  for (unsigned long i = 0; i < m->GetNumberOfPoints(); i++)
+    {
+    typename TMesh::PointType p;
+    m->GetPoint(i, &p);
+    for (int k = 0; k < 3; k++) out.push_back(p[k]);
+    }
+  return out;
+}
+
+static unsigned long differing_points(const std::vector<float> &a, const std::vector<float> &b)
+{
+  unsigned long n = 0;
+  for (size_t i = 0; i + 2 < a.size() && i + 2 < b.size(); i += 3)
+    if (a[i] != b[i] || a[i + 1] != b[i + 1] || a[i + 2] != b[i + 2]) n++;
+  return n;
+}
+
+static bool stale_gradient_switch(const char *vtkName)
+{
+  typedef itk::Image<float, 3> ImageType;
+  typedef itk::Mesh<float, 3> MeshType;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType> FilterType;
+  ImageType::Pointer first = stale_field(26, 22, 20, 12.5, 7.0), second = stale_field(31, 24, 21, 15.0, 8.5);
+  FilterType::Pointer stale = FilterType::New(), fresh = FilterType::New();
+  FilterType *both[2] = {stale.GetPointer(), fresh.GetPointer()};
+  for (int i = 0; i < 2; i++)
+    {
+    both[i]->SetIsoSurfaceValue(0.0f);
+    both[i]->GenerateTriangleFacesOff();
+    both[i]->SetProjectVertexSurfaceDistanceThreshold(0.01);
+    both[i]->SetProjectVertexStepLength(0.25);
+    }
+  stale->ReproduceStaleGradientOn();
+  stale->SetInput(first);
+  stale->Update();
+  stale->SetInput(second);
+  stale->Update();
+  if (vtkName) stale->WriteLastMeshAsVTKPolyData(vtkName, 2);
+  const std::vector<float> kept = flat_points(stale->GetOutput());
+  const unsigned long keptCells = stale->GetOutput()->GetNumberOfCells();
+  fresh->SetInput(second);
+  fresh->Update();
+  const std::vector<float> own = flat_points(fresh->GetOutput());
+  const unsigned long moved = differing_points(kept, own);
+  bool ok = kept.size() == own.size() && keptCells == fresh->GetOutput()->GetNumberOfCells() && moved > 0;
+  stale->ReproduceStaleGradientOff();              // (Modified(): the next Update() runs again, on the input's own gradient)
+  stale->Update();
+  const std::vector<float> back = flat_points(stale->GetOutput());
+  ok = ok && back.size() == own.size() && differing_points(back, own) == 0;
+  std::cout << "stale-gradient " << kept.size() / 3 << " " << keptCells << " moved " << moved
+            << (ok ? " consistent" : " INCONSISTENT") << std::endl;
+  return ok;
+}
+
+int main(int argc, char **argv)
 {
   try
     {
     bool ok = true;
+    ok &= stale_gradient_switch(argc > 1 ? argv[1] : 0);
     ok &= mesh_outlives_the_filter();
     ok &= dynamic_traits_mesh_equals_static();
     unsigned long p[9], c[9];

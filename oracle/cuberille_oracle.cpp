@@ -363,6 +363,9 @@ struct CellObj { uint64_t ids[4]; };   // stands for one heap-allocated itk cell
 template <class T>
 struct Filter {
   Image<T> im;
+  Image<T> gim;                      // the image the gradient interpolator was created on: `im` itself on a filter's first
+                                     // projecting Update(); on later ones STILL that first image (quirk Q3, txx:484: the
+                                     // interpolator is only ever created while it is null)
   oracle_params prm;
   T iso;
   double step_length;
@@ -377,7 +380,7 @@ struct Filter {
   // `dim` first, then the smoothing filters along the other axes in ascending order, float images in between; the
   // result divided by the spacing of `dim`; the direction matrix applied to the vector at the end
   void ComputeGradientImageRecursiveGaussian() {
-    const Geometry &g = im.g;
+    const Geometry &g = gim.g;
     const size_t N = (size_t)g.n[0] * g.n[1] * g.n[2];
     double sigma = g.spacing[0];                              // txx:489: m_MaxSpacing * 1.0
     for (int i = 1; i < 3; i++) sigma = sigma > g.spacing[i] ? sigma : g.spacing[i];
@@ -385,7 +388,7 @@ struct Filter {
     std::vector<float> a(N), b(N);
     for (int dim = 0; dim < 3; dim++) {
       const Deriche dc = deriche_setup(sigma, g.spacing[dim], 1, true);       // txx:490: NormalizeAcrossScale
-      const T *px = im.px;
+      const T *px = gim.px;
       deriche_pass(g, dc, dim, [&](idx_t i) { return (double)px[i]; }, a.data());
       float *src = a.data(), *dst = b.data();
       for (int ax = 0; ax < 3; ax++) {
@@ -413,9 +416,9 @@ struct Filter {
   void NormalAt(const double p[3], double nd[3]) {
     if (prm.gradient_variant == 1) {
       double ci[3];
-      point_to_cindex(im.g, p, ci);
+      point_to_cindex(gim.g, p, ci);
       Cell8 c;
-      make_cell(im.g, ci, c);
+      make_cell(gim.g, ci, c);
       double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
       for (unsigned counter = 0; counter < 8; counter++) {
         double overlap = 1.0;
@@ -425,7 +428,7 @@ struct Filter {
           else                     { ni[k] = c.lo[k]; overlap *= 1.0 - c.d[k]; }
         }
         if (overlap) {
-          const double *gp = &gradD[3 * ((ni[2] * im.g.n[1] + ni[1]) * im.g.n[0] + ni[0])];
+          const double *gp = &gradD[3 * ((ni[2] * gim.g.n[1] + ni[1]) * gim.g.n[0] + ni[0])];
           for (int k = 0; k < 3; k++) acc[k] += overlap * gp[k];
           total += overlap;
         }
@@ -437,7 +440,7 @@ struct Filter {
       for (int k = 0; k < 3; k++) nd[k] = acc[k] / norm;
     } else {
       float normal[3];
-      interpolate_gradient(im.g, grad.data(), p, normal);
+      interpolate_gradient(gim.g, grad.data(), p, normal);
       normalize(normal);
       for (int k = 0; k < 3; k++) nd[k] = (double)normal[k];
     }
@@ -446,7 +449,7 @@ struct Filter {
   // txx:478-498 (whole image, threads over z like ITK's ThreadedGenerateData)
   void ComputeGradientImage() {
     if (prm.gradient_variant == 1) { ComputeGradientImageRecursiveGaussian(); return; }
-    const Geometry &g = im.g;
+    const Geometry &g = gim.g;
     grad.resize((size_t)3 * g.n[0] * g.n[1] * g.n[2]);
     int nt = prm.gradient_threads > 0 ? prm.gradient_threads : 1;
     if (nt > g.n[2]) nt = (int)g.n[2];
@@ -454,7 +457,7 @@ struct Filter {
       for (idx_t z = z0; z < z1; z++)
         for (idx_t y = 0; y < g.n[1]; y++)
           for (idx_t x = 0; x < g.n[0]; x++)
-            gradient_at_index(im, x, y, z, &grad[3 * ((z * g.n[1] + y) * g.n[0] + x)]);
+            gradient_at_index(gim, x, y, z, &grad[3 * ((z * g.n[1] + y) * g.n[0] + x)]);
     };
     if (nt <= 1) { work(0, g.n[2]); return; }
     std::vector<std::thread> th;
@@ -683,10 +686,15 @@ double now_s() {
 }
 
 template <class T>
-int run_typed(const oracle_image *img, const oracle_params *prm, oracle_mesh *out) {
+int run_typed(const oracle_image *img, const oracle_image *gradient_of, const oracle_params *prm, oracle_mesh *out) {
   Filter<T> f;
   f.im.g = make_geometry(img);
   f.im.px = (const T *)img->voxels;
+  f.gim = f.im;
+  if (gradient_of) {
+    f.gim.g = make_geometry(gradient_of);
+    f.gim.px = (const T *)gradient_of->voxels;
+  }
   f.prm = *prm;
   // m_IsoSurfaceValue is an InputPixelType (h:180-181); the 64-bit integer types get theirs as an integer
   if (std::is_integral<T>::value && sizeof(T) == 8) f.iso = (T)prm->iso_value_int;
@@ -749,18 +757,23 @@ bool valid_image(const oracle_image *img) {
 
 extern "C" {
 
-int cuberille_oracle_run(const oracle_image *img, const oracle_params *prm, oracle_mesh *out) {
+int cuberille_oracle_run_after(const oracle_image *img, const oracle_image *first, const oracle_params *prm, oracle_mesh *out) {
   if (!valid_image(img) || !prm || !out) return 1;
+  if (first && (!valid_image(first) || first->pixel_type != img->pixel_type)) return 1;   // one filter object, one TInputImage
   std::memset(out, 0, sizeof(*out));
   if (prm->gradient_variant < 0 || prm->gradient_variant > 1) return 1;
   if (prm->gradient_variant == 1 && prm->project_vertices)      // ITK: "the number of pixels along a direction must be >= 4"
-    for (int i = 0; i < 3; i++) if (img->dims[i] < 4) return 1;
+    for (int i = 0; i < 3; i++) if ((first ? first : img)->dims[i] < 4) return 1;
   int err = 0;
   int rc = dispatch(img->pixel_type, [&](auto *tag) {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    return run_typed<T>(img, prm, out);
+    return run_typed<T>(img, first, prm, out);
   }, err);
   return err ? err : rc;
+}
+
+int cuberille_oracle_run(const oracle_image *img, const oracle_params *prm, oracle_mesh *out) {
+  return cuberille_oracle_run_after(img, nullptr, prm, out);
 }
 
 void cuberille_oracle_free(oracle_mesh *m) {

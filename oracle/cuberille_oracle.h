@@ -76,6 +76,11 @@ typedef struct {
 
 /* returns 0 on success, non-zero on bad arguments */
 int cuberille_oracle_run(const oracle_image *img, const oracle_params *prm, oracle_mesh *out);
+/* A LATER Update() of a filter object whose first projecting Update() ran on `first` (same pixel type; size and geometry
+ * may differ): quirk Q3 -- ComputeGradientImage() only builds the gradient interpolator while it is null (txx:484), so
+ * the walk of every later update follows the gradient image, and the geometry, of that first input.  first == NULL: the
+ * first update itself (= cuberille_oracle_run). */
+int cuberille_oracle_run_after(const oracle_image *img, const oracle_image *first, const oracle_params *prm, oracle_mesh *out);
 void cuberille_oracle_free(oracle_mesh *m);
 
 /* Single ITK-contract pieces exposed for unit tests (H7: one named function per [ITK] item). */

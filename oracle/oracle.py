@@ -60,6 +60,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.cuberille_oracle_run.argtypes = [C.POINTER(_Image), C.POINTER(_Params), C.POINTER(_Mesh)]
         _lib.cuberille_oracle_run.restype = C.c_int
+        _lib.cuberille_oracle_run_after.argtypes = [C.POINTER(_Image), C.POINTER(_Image), C.POINTER(_Params), C.POINTER(_Mesh)]
+        _lib.cuberille_oracle_run_after.restype = C.c_int
         _lib.cuberille_oracle_free.argtypes = [C.POINTER(_Mesh)]
         _lib.cuberille_oracle_interpolate.argtypes = [C.POINTER(_Image), C.POINTER(C.c_double)]
         _lib.cuberille_oracle_interpolate.restype = C.c_double
@@ -91,8 +93,10 @@ class OracleMesh:
 
 def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50,
         spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), gradient_threads=1,
-        faithful_cells=False, variant=0, gradient=0):
-    """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  variant: 0 the default projection,
+        faithful_cells=False, variant=0, gradient=0, first=None):
+    """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  first: None, or the input of the filter object's
+    FIRST projecting Update() as (vol, spacing, origin, direction) -- quirk Q3 (txx:484): this update then walks along
+    that image's gradient.  variant: 0 the default projection,
     1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches.  gradient: 0 the
     central differences of itk::GradientImageFilter, 1 USE_GRADIENT_RECURSIVE_GAUSSIAN (compiled out upstream too)."""
     img, keep = _image(vol, spacing, origin, direction)
@@ -109,7 +113,14 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     prm = _Params(float(iso), int(bool(triangles)), int(bool(project)), float(threshold), float(step),
                   float(relax), int(max_steps), int(gradient_threads), int(bool(faithful_cells)), int(variant), int(gradient), iso_int)
     mesh = _Mesh()
-    rc = lib().cuberille_oracle_run(C.byref(img), C.byref(prm), C.byref(mesh))
+    if first is not None:
+        fvol, *fgeo = first if isinstance(first, (tuple, list)) else (first,)
+        fgeo = list(fgeo) + [(1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3)][len(fgeo):]
+        fimg, fkeep = _image(np.asarray(fvol), *fgeo)
+        rc = lib().cuberille_oracle_run_after(C.byref(img), C.byref(fimg), C.byref(prm), C.byref(mesh))
+        del fkeep
+    else:
+        rc = lib().cuberille_oracle_run(C.byref(img), C.byref(prm), C.byref(mesh))
     if rc != 0:
         raise ValueError("cuberille_oracle_run failed: %d" % rc)
     try:

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 11
+    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_the_header(pkg):

@@ -311,6 +311,62 @@ def test_default_walk_restatement_matches_the_oracle(oracle):
     assert got.info["proj_iterations"] == passes
 
 
+def _other_field():
+    """A smaller, shifted neighbour of _small_field (9 x 10 x 8 voxels): as the FIRST input of a filter object its gradient image
+    does not cover the second input's surface everywhere -- the cached interpolator clamps to its own extent (I5)."""
+    z, y, x = np.meshgrid(np.arange(8, dtype=np.float64), np.arange(10, dtype=np.float64), np.arange(9, dtype=np.float64), indexing="ij")
+    return (3.0 - np.sqrt((x - 4.5) ** 2 + 0.8 * (y - 4.0) ** 2 + (z - 3.75) ** 2) + 0.1 * np.cos(1.1 * x + 0.7 * z)).astype(np.float32)
+
+
+def test_second_update_walks_along_the_first_inputs_gradient(oracle):
+    """Quirk Q3 (txx:484): ComputeGradientImage() builds the gradient interpolator only while it is null, so a LATER Update()
+    of the same filter object walks along the gradient image -- through the geometry -- of the first projecting update's
+    input.  cuberille_oracle_run_after against the Python restatement: normal from the FIRST volume's gradient image at the
+    point's continuous index IN THAT IMAGE (clamped to its extent), value from the current volume."""
+    vol, first = _small_field(), _other_field()
+    kw = dict(threshold=0.01, step=0.3, relax=0.9, max_steps=14)
+    flat = oracle.run(vol, 0.0, triangles=False, project=False, **kw)
+    own = oracle.run(vol, 0.0, triangles=False, project=True, **kw)
+    # the first update itself, and a "later" update whose first input was the same image: nothing to see
+    for same in (None, vol, (vol,), (vol, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3))):
+        again = oracle.run(vol, 0.0, triangles=False, project=True, first=same, **kw)
+        assert np.array_equal(again.points.view(np.uint32), own.points.view(np.uint32)) and np.array_equal(again.cells, own.cells)
+    for origin in [(0.0, 0.0, 0.0), (1.0, -0.5, 2.0)]:
+        got = oracle.run(vol, 0.0, triangles=False, project=True, first=(first, (1.0, 1.0, 1.0), origin), **kw)
+        assert np.array_equal(got.cells, flat.cells)
+        assert not np.array_equal(got.points, own.points)
+        passes = 0
+        for i, v in enumerate(flat.points):
+            v, step, steps, n = [float(c) for c in v], kw["step"], 0, 0
+            while True:
+                n += 1
+                nrm = _py_normal(oracle, first, [v[k] - origin[k] for k in range(3)])
+                value = oracle.interpolate(vol, tuple(v))
+                if abs(value - 0.0) < kw["threshold"]:
+                    break
+                sign = 1.0 if value < 0.0 else -1.0
+                with np.errstate(all="ignore"):
+                    v = [_f32(v[k] + (nrm[k] * sign * step)) for k in range(3)]
+                step *= kw["relax"]
+                steps += 1
+                if steps - 1 > kw["max_steps"]:
+                    break
+            passes += n
+            assert np.array_equal(np.asarray(v, dtype=np.float32).view(np.uint32), got.points[i].view(np.uint32)), (origin, i)
+        assert got.info["proj_iterations"] == passes
+    # not projecting: the gradient image is never looked at; another pixel type than the filter's is not a later update of it
+    off = oracle.run(vol, 0.0, triangles=True, project=False, first=first, **kw)
+    assert_flat = oracle.run(vol, 0.0, triangles=True, project=False, **kw)
+    assert np.array_equal(off.points, assert_flat.points) and np.array_equal(off.cells, assert_flat.cells)
+    with pytest.raises(ValueError):
+        oracle.run(vol, 0.0, first=first.astype(np.float64), **kw)
+    # the compiled-out branches and the other gradient go through the same cached interpolator
+    for extra in (dict(variant=1), dict(variant=2), dict(gradient=1)):
+        a = oracle.run(vol, 0.0, triangles=False, project=True, first=first, **dict(kw, **extra))
+        b = oracle.run(vol, 0.0, triangles=False, project=True, **dict(kw, **extra))
+        assert np.array_equal(a.cells, b.cells) and not np.array_equal(a.points, b.points), extra
+
+
 def test_recursive_gaussian_gradient_against_second_restatement(oracle):
     """USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491), compiled out upstream and with no fixture: the
     oracle's restatement of ITK's recursive Gaussian gradient + the walk through it against a second restatement in
