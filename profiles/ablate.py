@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--quads", action="store_true", help="quadrilateral cells (no split, no point gathers in the cell pass)")
+    ap.add_argument("--pass-only", action="store_true", help="no events between the stages (the production timing): "
+                    "ms_pass and ms_total only, the combinations interleaved round by round")
     ap.add_argument("sweeps", nargs="*")
     args = ap.parse_args()
     import torch
@@ -39,6 +41,24 @@ def main():
         names.append(k)
         values.append([int(x) for x in v.split(",")])
     keys = ["ms_classify", "ms_count", "ms_emit_points", "ms_project", "ms_emit_cells", "ms_total"]
+    if args.pass_only:
+        combos = list(itertools.product(*values)) if names else [()]
+        rows = {cb: [] for cb in combos}
+        for rnd in range(args.reps + 1):
+            for cb in combos:
+                ex.debug_option("defaults", 0)
+                for k, v in zip(names, cb):
+                    ex.debug_option(k, v)
+                for i in range(4):
+                    r = ex.extract_device(vol.data_ptr(), desc, prm)
+                    if rnd and i:
+                        rows[cb].append([r.ms_pass, r.ms_total])
+        for cb in combos:
+            a = np.array(rows[cb])
+            print(" ".join("%s=%d" % kv for kv in zip(names, cb)) or "defaults",
+                  "pass %.4f (min %.4f) total %.4f (min %.4f)" % (np.median(a[:, 0]), a[:, 0].min(), np.median(a[:, 1]), a[:, 1].min()),
+                  "points", r.n_points, flush=True)
+        return
     for combo in itertools.product(*values) if names else [()]:
         ex.debug_option("defaults", 0)
         ex.debug_option("stage_timing", 1)
