@@ -334,7 +334,14 @@ long long projection_reach(const Geo &geo, const Params &p) {
   else if (p.relax <= 0.0) travel = p.step;
   else travel = p.step * (1.0 - std::pow(p.relax, n)) / (1.0 - p.relax);
   const double rowNorm = std::sqrt(geo.p2i[6] * geo.p2i[6] + geo.p2i[7] * geo.p2i[7] + geo.p2i[8] * geo.p2i[8]);
-  const double slices = std::ceil(travel * rowNorm);
+  // Where the walk STARTS: the reference moves the corner's index position to physical space and takes half a spacing off
+  // every PHYSICAL axis (txx:266-270) -- half a voxel back along every index axis only while the direction matrix is the
+  // identity.  Under a tilted direction the start lies row_z(PhysicalPointToIndex) . spacing/2 slices below the corner's
+  // index instead of 1/2: with spacing (3, 1.7, 0.25) up to ten slices away from the lattice corner (found by
+  // tests/fuzz_campaign.py, round 5: slabs cut to the old figure clamped four walks of a 19-slice volume).
+  const double startOff = (geo.p2i[6] * geo.spacing[0] + geo.p2i[7] * geo.spacing[1] + geo.p2i[8] * geo.spacing[2]) * 0.5;
+  const double astray = std::fabs(startOff - 0.5);
+  const double slices = std::ceil(travel * rowNorm) + (astray < 1e-9 ? 0.0 : std::ceil(astray));
   if (!(slices < 1e9)) return 1000000000LL;
   return (long long)slices + 3;
 }

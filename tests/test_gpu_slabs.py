@@ -569,6 +569,47 @@ def test_slabs_under_a_tilted_direction_matrix(pkg, oracle, extractor):
     assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
 
 
+def test_slabs_where_the_walk_starts_slices_away_from_its_corner(pkg, oracle, extractor):
+    """Found by tests/fuzz_campaign.py (seed 1, case 1955): the reference takes half a spacing off every PHYSICAL axis of a corner
+    (txx:266-270); under a tilted direction with spacings (3, 1.7, 0.25) a vertex starts more than two slices away from its
+    lattice corner.  cuberille_required_halo now counts that: slabs carrying exactly the halo it names -- thick and two slices
+    thin -- reproduce the whole-volume mesh bit for bit."""
+    import torch
+    direction = np.array([[-0.938553308377216, 0.29130696674791057, 0.18508900145150348],
+                          [-0.2721283976390384, -0.29475640305213213, -0.9160048024209143],
+                          [-0.21228241220739966, -0.9100873111871742, 0.35591749533214434]])
+    rng = np.random.default_rng(5)
+    z, y, x = np.meshgrid(np.arange(19.0), np.arange(8.0), np.arange(65.0), indexing="ij")
+    vox = np.rint(40.0 * np.sin(0.35 * x + 0.5 * y) * np.cos(0.45 * z) + rng.normal(0, 6, size=z.shape)).astype(np.int8)
+    nz, ny, nx = vox.shape
+    for spacing, d in [((3.0, 1.7, 0.25), direction), ((3.0, 1.7, 0.25), direction.T)]:
+        geo = dict(spacing=spacing, origin=(-2.451, 5.471, 0.531), direction=d)
+        kw = dict(triangles=1, project=1, threshold=0.0, step=0.0625, relax=0.95, max_steps=25)
+        prm = pkg.make_params(0, **kw)
+        ref = oracle.run(vox, 0, **geo, **kw)
+        below, above = pkg.required_halo(pkg.make_desc(np.int8, (nx, ny, nz), **geo), prm)
+        assert below >= 10 and below < nz
+        dev = torch.from_numpy(vox).cuda()
+        for cuts in ([0, 9, 19], [0, 9, 15, 17, 19], [0, 2, 4, 19]):
+            pts, cells, poff = [], [], 0
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                lo, hi = max(a - below, 0), min(b + above, nz)
+                n_p, n_c = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.int8, (nx, ny, hi - lo), **geo), prm,
+                                           pkg._abi.Slab(nz, lo, a, b, 0, 0))
+                extractor.emit(poff)
+                m = extractor.download()
+                pts.append(m.points)
+                cells.append(m.cells)
+                poff += n_p
+            assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+        # one slice less than asked for is refused, not clamped
+        if 9 + above <= nz:
+            with pytest.raises(pkg._abi.CuberilleError) as e:
+                extractor.count(dev[0:9 + above - 1].data_ptr(), pkg.make_desc(np.int8, (nx, ny, 9 + above - 1), **geo), prm,
+                                pkg._abi.Slab(nz, 0, 0, 9, 0, 0))
+            assert e.value.code == pkg._abi.ERR_HALO
+
+
 def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
     """cuberille_emit_points between count and emit (the multi-GPU driver calls it before the count all-gather): the
     vertices are scattered and projected without the id offsets, cuberille_emit adds the cells -- same mesh as without

@@ -98,6 +98,48 @@ def test_required_halo_follows_the_parameters(pkg):
     assert pkg.required_halo(d, pkg.make_params(0.5, step=0.25, relax=0.95, max_steps=0))[0] == 1 + 3
 
 
+def test_required_halo_covers_the_start_of_the_walk_under_a_tilted_direction(pkg, oracle):
+    """The reference takes half a spacing off every PHYSICAL axis of a corner's position (txx:266-270): under a tilted
+    direction matrix with unequal spacings the walk starts slices away from the lattice corner, not half a voxel.  A slab cut
+    to the old figure clamped such walks (found by tests/fuzz_campaign.py, seed 1 case 1955).  Property, on the oracle's
+    meshes: no vertex starts or ends further (in slices) from the voxel slice that created it than the halo allows for
+    -- the cell's far side and the gradient ring (2) taken off."""
+    direction = np.array([[-0.938553308377216, 0.29130696674791057, 0.18508900145150348],
+                          [-0.2721283976390384, -0.29475640305213213, -0.9160048024209143],
+                          [-0.21228241220739966, -0.9100873111871742, 0.35591749533214434]])
+    rng = np.random.default_rng(5)
+    z, y, x = np.meshgrid(np.arange(19.0), np.arange(8.0), np.arange(40.0), indexing="ij")
+    vox = np.rint(40.0 * np.sin(0.35 * x + 0.5 * y) * np.cos(0.45 * z) + rng.normal(0, 6, size=z.shape)).astype(np.int8)
+    cases = [((3.0, 1.7, 0.25), direction), ((3.0, 1.7, 0.25), direction.T), ((0.5, 2.0, 1.0), direction),
+             ((1.0, 1.0, 1.0), direction), ((3.0, 1.7, 0.25), np.eye(3))]
+    for spacing, d in cases:
+        kw = dict(triangles=False, threshold=0.0, step=0.25 * min(spacing), relax=0.95, max_steps=25)
+        desc = pkg.make_desc(np.int8, (40, 8, 19), spacing, (1.0, -2.0, 0.5), d)
+        below, above = pkg.required_halo(desc, pkg.make_params(0, **kw))
+        geo = dict(spacing=spacing, origin=(1.0, -2.0, 0.5), direction=d)
+        start = oracle.run(vox, 0, project=False, **geo, **kw).points.astype(np.float64)
+        end = oracle.run(vox, 0, project=True, **geo, **kw).points.astype(np.float64)
+        minv = np.linalg.inv(d @ np.diag(spacing))
+        zs = ((start - np.array(geo["origin"])) @ minv.T)[:, 2]
+        ze = ((end - np.array(geo["origin"])) @ minv.T)[:, 2]
+        # a vertex is created by a voxel of slice k with its corner at lattice k or k + 1: with the identity that is index
+        # k - 1/2 or k + 1/2; whatever the direction, the creating slice lies within one of the lattice plane
+        ident = np.array_equal(d, np.eye(3))
+        lattice = np.rint(zs + 0.5) if ident else None
+        if ident:
+            assert np.abs(zs - (lattice - 0.5)).max() < 1e-6
+            assert (below, above) == pkg.required_halo(pkg.make_desc(np.int8, (40, 8, 19), spacing), pkg.make_params(0, **kw))
+        else:
+            # the start positions under the identity name the lattice corners (same volume, same creation order)
+            s0 = oracle.run(vox, 0, project=False, spacing=spacing, **kw).points.astype(np.float64)
+            lattice = np.rint(s0[:, 2] / spacing[2] + 0.5)
+        far = np.maximum(np.abs(zs - (lattice - 0.5)), np.abs(ze - (lattice - 0.5))).max()
+        assert far + 2.0 <= min(below, above), (spacing, far, below, above)
+    # ... and the figure the campaign's case needed
+    desc = pkg.make_desc(np.int8, (65, 8, 19), (3.0, 1.7, 0.25), (-2.451, 5.471, 0.531), direction)
+    assert pkg.required_halo(desc, pkg.make_params(0, threshold=0.0, step=0.0625, relax=0.95, max_steps=25)) == (10, 10)
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under the package may reference it."""
     pkg_dir = os.path.join(ROOT, "midas-journal-740_amd")
