@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-voxels", type=int, default=900000)
+    ap.add_argument("--big", action="store_true", help="up to 120 rows and slices (fewer, larger cases: set --max-voxels too)")
     args = ap.parse_args()
     import torch
     pkg = graft.load_package()
@@ -128,8 +129,8 @@ def main():
         while time.time() - t0 < args.seconds:
             case += 1
             nx = int(rng.choice(XS))
-            ny = int(rng.integers(1, 41))
-            nz = int(rng.integers(1, 41))
+            ny = int(rng.integers(1, 121 if args.big else 41))
+            nz = int(rng.integers(1, 121 if args.big else 41))
             while nx * ny * nz > args.max_voxels:
                 ny = max(1, ny // 2)
                 nz = max(1, nz // 2)
@@ -142,7 +143,7 @@ def main():
                       threshold=float(rng.choice([0.0, 0.01, 0.2, 5.0])) * (1.0 if np.dtype(dt).kind != "f" else 0.05),
                       step=float(rng.choice([0.1, 0.25, 0.6, 1.3])) * min(spacing),
                       relax=float(rng.choice([0.5, 0.9, 0.95, 1.0])), max_steps=int(rng.choice([0, 1, 4, 25, 50])), variant=variant)
-            route = str(rng.choice(["host", "device", "stream", "slabs", "count_emit", "held", "switch"]))
+            route = str(rng.choice(["host", "device", "stream", "slabs", "thin_slabs", "count_emit", "held", "switch"]))
             vol = pkg.Volume(vox, spacing=spacing, origin=origin, direction=direction)
             okw = dict(kw, spacing=spacing, origin=origin, direction=direction)
             recipe = dict(case=case, seed=args.seed, shape=[nz, ny, nx], dtype=np.dtype(dt).name, iso=iso, route=route, kw=kw,
@@ -197,13 +198,14 @@ def main():
                     mesh = held.download()
                     recipe["first"] = dict(shape=list(fshape), spacing=fs, origin=fo, direction=fd.tolist())
                     ref = oracle.run(vox, iso, first=(fvox, fs, fo, fd), **okw)
-                else:   # slabs stitched by hand: counts, id offsets, concatenation
+                else:   # slabs stitched by hand: counts, id offsets, concatenation; thin: 3 + 3 halo slices, escaped walks again
+                    thin = route == "thin_slabs"
                     occupied = True
                     ins = vox >= (np.dtype(dt).type(iso) if np.dtype(dt).kind != "f" else iso)
                     if np.dtype(dt).kind == "f":
                         ins = ins & ~np.isnan(vox)
                     occupied = bool(ins.reshape(nz, -1).any(axis=1).all())
-                    if nz < 3 or not occupied or variant != 0 and rng.random() < 0.5:
+                    if nz < 3 or not occupied or variant != 0 and (thin or rng.random() < 0.5):
                         route = recipe["route"] = "host"        # (quirk Q1 across a cut needs the ranks' protocol: tests/test_gpu_slabs.py)
                         ex.extract_host(vol, prm)
                         mesh = ex.download()
@@ -213,11 +215,20 @@ def main():
                         cuts = [0] + sorted(set(int(v) for v in rng.integers(1, nz, size=ncut))) + [nz]
                         recipe["cuts"] = cuts
                         pts, cells, poff = [], [], 0
+                        tb, ta = pkg.cuberille.minimum_halo(desc, prm)
                         for a, b in zip(cuts[:-1], cuts[1:]):
-                            lo, hi = max(a - below, 0), min(b + above, nz)
+                            lo, hi = (max(a - tb - 1, 0), min(b + ta + 1, nz)) if thin else (max(a - below, 0), min(b + above, nz))
                             dev = to_device(torch, vox[lo:hi])
                             sdesc = pkg.make_desc(vox.dtype, (nx, ny, hi - lo), spacing, origin, direction)
-                            n_p, n_c = ex.count(dev.data_ptr(), sdesc, prm, pkg._abi.Slab(nz, lo, a, b, 0, 0))
+                            n_p, n_c = ex.count(dev.data_ptr(), sdesc, prm, pkg._abi.Slab(nz, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO if thin else 0))
+                            if thin:
+                                ex.emit_points()
+                                n_esc = ex.escaped_count()
+                                stats["escaped_walks"] = stats.get("escaped_walks", 0) + int(n_esc)
+                                if n_esc:
+                                    dlo, dhi = max(a - below, 0), min(b + above, nz)
+                                    deep = to_device(torch, vox[dlo:dhi])
+                                    ex.reproject_escaped(deep.data_ptr(), dlo, dhi - dlo)
                             ex.emit(poff)
                             m = ex.download()
                             pts.append(m.points)
