@@ -995,7 +995,7 @@ int cuberille_emit(cuberille_ctx *c, uint64_t point_id_offset, cuberille_result 
   const bool needPlane = c->g.extAlias && c->aliasZ >= c->g.oz0;
   if (needPlane && (!c->extIds || !c->extPts))
     return fail(c, CUBERILLE_ERR_STATE, "cuberille_emit after cuberille_recount needs cuberille_set_alias_plane");
-  c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
+  c->slabMesh = point_id_offset != 0 || c->tot.V0 != 0 || part_of_a_volume(c->g);
   c->pointOffset = point_id_offset;
   rc = emit_points_phase(c);
   if (rc) return rc;
@@ -1192,7 +1192,7 @@ int step_end_impl(cuberille_ctx *c, const void *dev_rows, int n_ranks, int rank,
     if (res) *res = c->res;                             // the counts (what cuberille_count would have returned)
     return CUBERILLE_RETRY;
   }
-  c->slabMesh = off != 0 || c->tot.V0 != 0 || c->g.gnz != c->g.nzb;
+  c->slabMesh = off != 0 || c->tot.V0 != 0 || part_of_a_volume(c->g);
   c->pointOffset = off;
   return finish_result(c, res);
 }

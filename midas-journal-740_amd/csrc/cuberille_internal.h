@@ -42,6 +42,14 @@ struct Grid {
                        //    occupied slice (cuberille_recount)
 };
 
+// Is this context one rank of several (its row then carries the three slices the ranks above judge their flags by)?  NOT
+// "the buffer is shorter than the volume": with a halo as deep as the rest of the volume a rank's BUFFER is the whole volume
+// while it owns a part of it (round 5, tests/fuzz_ranks.py: a rank that owned slices 0-10 of 13 said "no occupied slice" and
+// the rank two above kept a count that quirk Q1 should have changed).
+__host__ __device__ inline bool part_of_a_volume(const Grid &g) {
+  return g.gnz != (long long)g.nzb || g.oz0 != 0 || g.oz1 != g.nzb;
+}
+
 struct Totals {        // device-resident, zeroed before every count, mirrored to pinned host memory
   u64 totV, totQ;      // created vertices / quads in the counted range
   u64 V0, Q0;          // of which before the first owned slice

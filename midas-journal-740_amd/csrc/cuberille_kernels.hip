@@ -1076,7 +1076,7 @@ __device__ void block_scan_tail(const u64 *blockTot, u64 *__restrict__ blockBase
   constexpr int NWAVES = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cz0 = g.cz0, oz0 = g.oz0, oz1 = g.oz1;
-  if (g.gnz != (long long)g.nzb) {
+  if (part_of_a_volume(g)) {
     // a SLAB's row: first occupied slice of the counted range, highest and second-highest occupied owned slice (row_flags)
     auto wave_min = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o < v ? o : v; } return v; };
     auto wave_max = [](int v) { for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(v, sft, 64); v = o > v ? o : v; } return v; };
@@ -3325,7 +3325,7 @@ hipError_t launch_count(const Workspace &w, const Grid &g, size_t nwords, int q1
   const unsigned chunks = blocks > SCAN_CHUNK ? (blocks + SCAN_CHUNK - 1) / SCAN_CHUNK : 1;
   if (chunks > 1) hipLaunchKernelGGL(k_block_partial, dim3(chunks), dim3(1024), 0, s, w.blockTot, blocks);
   hipLaunchKernelGGL(k_block_scan, dim3(chunks), dim3(1024), 0, s, w.blockTot, w.blockBase, blocks, g0, w.totals, gate, w.sliceOcc, g.cz0, g.oz0, g.oz1, g.zglob0,
-                     g.gnz != (long long)g.nzb ? 1 : 0);
+                     part_of_a_volume(g) ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -101,6 +101,19 @@ def halo_bytes(global_nz, world, rank, slice_bytes, halo=HALO, held=0, ranges=No
     return sum(b - a for _, a, b in recvs) * int(slice_bytes)
 
 
+def _gloo_reads_device_memory_now(tensor, group):
+    """gloo's point-to-point operations know nothing of streams: handed a device tensor (the rehearsals of the RCCL event path
+    on a one-GPU box, ShardedExtractor.force_event_path) its threads read the bytes straight away -- not behind what torch's
+    current stream was told to wait for, as an RCCL operation does.  So under gloo the host waits for that stream first: the
+    sweep that produces the bit planes, the copy that filled the owned slices.  (Found by tests/fuzz_ranks.py, round 5: two
+    meshes in six thousand random three-rank steps carried a neighbour's bit planes from BEFORE its sweep.)  A no-op under
+    RCCL and for host tensors."""
+    import torch
+    import torch.distributed as dist
+    if tensor is not None and tensor.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(tensor.device).synchronize()
+
+
 def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo=HALO, global_nz=None, held=0, ranges=None):
     """buf[z - lo] holds slice z for z in [lo, hi); the owned part [z0, z1) is valid on entry (and, held, that much halo
     around it).  Fills the rest of the halo (a number, or (below, above)) from the ranks that own those slices.  All
@@ -127,6 +140,7 @@ def exchange_halos(buf, lo, hi, z0, z1, rank, world, group=None, wait=True, halo
         t = buf[a - lo:b - lo].contiguous()
         keep.append(t)
         ops.append(dist.P2POp(dist.isend, t, peer, group))
+    _gloo_reads_device_memory_now(buf, group)
     reqs = dist.batch_isend_irecv(ops) if ops else []
     if not wait:
         return reqs, keep
@@ -606,6 +620,8 @@ class ShardedExtractor:
             t = plane(a, b).cpu() if staged else plane(a, b)
             keep.append(t)
             ops.append(dist.P2POp(dist.isend, t, peer, group))
+        if not staged and keep:
+            _gloo_reads_device_memory_now(keep[0], group)
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if not wait:
             return reqs, keep

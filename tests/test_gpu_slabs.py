@@ -610,6 +610,50 @@ def test_slabs_where_the_walk_starts_slices_away_from_its_corner(pkg, oracle, ex
             assert e.value.code == pkg._abi.ERR_HALO
 
 
+def test_a_rank_whose_buffer_is_the_whole_volume_still_reports_its_slices(pkg, extractor):
+    """Found by tests/fuzz_ranks.py (seed 1, case 3726): three ranks own slices 0-10, 11 and 12 of 13; slices 8-11 are empty, so
+    the top rank's only slice has its quirk-Q1 source (slice 7) below its buffer and flags ERRF_ALIAS_BELOW_BUFFER -- to be
+    judged against the rows of the ranks below.  With a halo as deep as the rest of the volume rank 0's BUFFER is the whole
+    volume; the block scan took "buffer == volume" for "no neighbours" and left its row's three slices at -1: no source in
+    sight, the flag was dropped and the device-resident step kept a count the reference's aliasing changes.  The row now
+    carries them whenever the owned range is a part, and every rank's cuberille_step_end sends the step to the host."""
+    import struct
+    import torch
+    from midas_journal_740_amd.distributed import _words_view
+    rng = np.random.default_rng(3726)
+    nz, ny, nx = 13, 13, 200
+    vox = (rng.random((nz, ny, nx)) < 0.3).astype(np.uint16) * 200
+    vox[8:12] = 0
+    prm = pkg.make_params(121, triangles=True, project=True, threshold=5.0, step=0.025, relax=0.95, max_steps=4)
+    geo = dict(spacing=(1.7, 0.25, 3.0), origin=(3.331, -0.596, 4.105))
+    bounds = [(0, 11), (11, 12), (12, 13)]
+    halo = max(pkg.required_halo(pkg.make_desc(np.uint16, (nx, ny, nz), **geo), prm))
+    assert halo == 4
+    exs = [extractor, pkg.Extractor(0), pkg.Extractor(0)]
+    try:
+        rows = torch.zeros(3 * 96, dtype=torch.uint8, device="cuda")
+        keep = []
+        for r, (a, b) in enumerate(bounds):
+            lo, hi = max(a - halo, 0), min(b + halo, nz)
+            dev = torch.from_numpy(vox[lo:hi].view(np.int16)).cuda()
+            keep.append(dev)
+            ptr, n = exs[r].step_begin(dev.data_ptr(), pkg.make_desc(np.uint16, (nx, ny, hi - lo), **geo), prm, pkg._abi.Slab(nz, lo, a, b, 0, 0))
+            assert n == 96
+            torch.cuda.synchronize()
+            rows[r * 96:(r + 1) * 96] = _words_view(ptr, 12, dev.device).view(torch.uint8)
+        torch.cuda.synchronize()
+        raw = rows.cpu().numpy().tobytes()
+        parsed = [struct.unpack_from("<6Q4I2Q3iI", raw, r * 96) for r in range(3)]
+        assert [p[12:15] for p in parsed] == [(0, 7, 6), (-1, -1, -1), (12, 12, -1)]     # aliasZ, topZ, top2Z
+        assert parsed[2][6] & 2 and not parsed[0][6] & 2 and not parsed[1][6] & 2          # ERRF_ALIAS_BELOW_BUFFER on the top rank only
+        for r in range(3):
+            res, done = exs[r].step_end(rows.data_ptr(), 3, r)
+            assert not done                                                                  # CUBERILLE_RETRY everywhere: the host takes over
+    finally:
+        for e in exs[1:]:
+            e.close()
+
+
 def test_emit_points_ahead_of_the_offsets(pkg, oracle, extractor, volumes):
     """cuberille_emit_points between count and emit (the multi-GPU driver calls it before the count all-gather): the
     vertices are scattered and projected without the id offsets, cuberille_emit adds the cells -- same mesh as without
