@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-voxels", type=int, default=900000)
+    ap.add_argument("--recursive-gaussian", action="store_true", help="every case that can takes the recursive-Gaussian gradient (h:21)")
     ap.add_argument("--big", action="store_true", help="up to 120 rows and slices (fewer, larger cases: set --max-voxels too)")
     args = ap.parse_args()
     import torch
@@ -144,6 +145,8 @@ def main():
                       step=float(rng.choice([0.1, 0.25, 0.6, 1.3])) * min(spacing),
                       relax=float(rng.choice([0.5, 0.9, 0.95, 1.0])), max_steps=int(rng.choice([0, 1, 4, 25, 50])), variant=variant)
             route = str(rng.choice(["host", "device", "stream", "slabs", "thin_slabs", "count_emit", "held", "switch"]))
+            if args.recursive_gaussian and project and min(nx, ny, nz) >= 4 and route in ("host", "device", "stream", "count_emit", "switch"):
+                kw["gradient"] = 1                         # USE_GRADIENT_RECURSIVE_GAUSSIAN (whole volumes, four voxels along every axis)
             vol = pkg.Volume(vox, spacing=spacing, origin=origin, direction=direction)
             okw = dict(kw, spacing=spacing, origin=origin, direction=direction)
             recipe = dict(case=case, seed=args.seed, shape=[nz, ny, nx], dtype=np.dtype(dt).name, iso=iso, route=route, kw=kw,
