@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CUBERILLE_ABI_VERSION 12
+#define CUBERILLE_ABI_VERSION 13
 
 /* status codes (reference behaviour: the filter has no explicit checks and ITK throws
  * itk::ExceptionObject, Testing/CuberilleTest01.cxx:207-212; the C++ wrapper turns a
@@ -68,6 +68,12 @@ typedef struct {
   double spacing[3];
   double origin[3];
   double direction[9];    /* row-major direction cosines */
+  int64_t index_start[3]; /* GetBufferedRegion().GetIndex(): the ITK index of the buffer's first pixel (0 for an image as read from
+                             a file; a cropped or pasted image keeps the index of where it came from).  origin stays the
+                             image's GetOrigin() -- the physical position of INDEX 0: TransformIndexToPhysicalPoint (txx:266)
+                             and the interpolators (txx:451,455) see position + index_start, as in ITK.  Within +-2^30.
+                             (ABI 13; before, a caller moved the origin to the first buffered pixel: the same mesh up to the
+                             last bit of a double in the transforms.) */
 } cuberille_image_desc;
 
 /* The filter's parameters: h:180-228, constructor defaults txx:33-40. */

@@ -30,12 +30,12 @@ EXPORTS = [
     "cuberille_slice_counts", "cuberille_failed_row", "cuberille_warm_up", "cuberille_mesh_host", "cuberille_step_classify", "cuberille_step_count",
     "cuberille_release_host_mesh", "cuberille_hold_gradient", "cuberille_gradient_held",
 ]
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ImageDesc(C.Structure):
     _fields_ = [("pixel_type", C.c_int32), ("dims", C.c_int64 * 3), ("spacing", C.c_double * 3),
-                ("origin", C.c_double * 3), ("direction", C.c_double * 9)]
+                ("origin", C.c_double * 3), ("direction", C.c_double * 9), ("index_start", C.c_int64 * 3)]
 
 
 class Params(C.Structure):

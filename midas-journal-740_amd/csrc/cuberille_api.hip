@@ -215,6 +215,8 @@ int validate(cuberille_ctx *c, const cuberille_image_desc *img, const void *vox,
     if (img->dims[i] < 1) return fail(c, CUBERILLE_ERR_ARGUMENT, "image dimensions must be >= 1");
     if (img->dims[i] > 0x7fffffffLL) return fail(c, CUBERILLE_ERR_LIMIT, "image dimension exceeds 2^31-1");
     if (!(img->spacing[i] > 0.0)) return fail(c, CUBERILLE_ERR_ARGUMENT, "spacing must be > 0");
+    if (img->index_start[i] < -(1LL << 30) || img->index_start[i] > (1LL << 30))
+      return fail(c, CUBERILLE_ERR_LIMIT, "the buffered region's start index must lie within +-2^30");
   }
   if (prm->projection_variant < CUBERILLE_PROJECT_DEFAULT || prm->projection_variant > CUBERILLE_PROJECT_LINESEARCH)
     return fail(c, CUBERILLE_ERR_ARGUMENT, "unknown projection variant");
@@ -353,6 +355,8 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
     geo.spacing[i] = img->spacing[i];
     geo.origin[i] = img->origin[i];
     geo.gcoef[i] = (float)(0.5 * (1.0 / img->spacing[i]));
+    geo.istart[i] = (int)img->index_start[i];
+    geo.start[i] = (double)img->index_start[i];
     if (img->spacing[i] > maxSpacing) maxSpacing = img->spacing[i];
   }
   for (int i = 0; i < 9; i++) geo.dir[i] = img->direction[i];

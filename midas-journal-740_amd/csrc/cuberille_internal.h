@@ -22,6 +22,8 @@ struct Geo {
   double spacing[3];
   double dir[9];
   float gcoef[3];     // derivative tap coefficient per axis: float(0.5 * (1/spacing))
+  int istart[3];      // index of the first buffered pixel (itk::ImageRegion::GetIndex): ITK's index <-> point transforms and
+  double start[3];    // its interpolators work on INDICES = buffer position + start (the same integers, as int and double)
 };
 
 // Layout of the packed inside-bit volume and of the slab being processed.

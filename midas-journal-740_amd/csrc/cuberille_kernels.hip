@@ -1802,7 +1802,8 @@ __device__ __forceinline__ int getbit(const u64 *__restrict__ bits, const Grid &
 
 // I3 + txx:268-270: lattice corner -> physical point - spacing/2, in the mesh's float coordinates
 __device__ __forceinline__ void corner_point(const Geo &geo, long long cx, long long cy, long long cz, float p[3]) {
-  const double idx[3] = {(double)cx, (double)cy, (double)cz};
+  // (cx, cy, cz: positions in the volume; TransformIndexToPhysicalPoint takes the INDEX, position + region start)
+  const double idx[3] = {(double)cx + geo.start[0], (double)cy + geo.start[1], (double)cz + geo.start[2]};
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     double sum = 0.0;
@@ -2355,7 +2356,8 @@ __device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const in
     int bi;
     asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(bi) : "v"(b));
     const int end = n[k] - 1;
-    const int bc = min(max(bi, -1), end);
+    // (the interpolators clamp into [StartIndex, EndIndex] of the buffered region: as a position in the volume)
+    const int bc = min(max(bi - geo.istart[k], -1), end);
     c.bc[k] = bc;
     c.lo[k] = max(bc, 0);
     c.hi[k] = min(bc + 1, end);

@@ -119,7 +119,7 @@ def check_iso(pixel_type, params):
         raise _abi.CuberilleError(_abi.ERR_ARGUMENT, "iso value is not representable in the pixel type")
 
 
-def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
+def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None, index_start=(0, 0, 0)):
     d = _abi.ImageDesc()
     d.pixel_type = PIXEL_CODES[np.dtype(np_dtype)]
     d.dims[:] = [int(v) for v in dims_xyz]
@@ -127,6 +127,7 @@ def make_desc(np_dtype, dims_xyz, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0
     d.origin[:] = [float(v) for v in origin]
     dm = np.eye(3) if direction is None else np.asarray(direction, dtype=np.float64)
     d.direction[:] = [float(v) for v in dm.reshape(9)]
+    d.index_start[:] = [int(v) for v in index_start]        # (x, y, z) of GetBufferedRegion().GetIndex(); 0 for files
     return d
 
 
@@ -179,7 +180,7 @@ class Extractor:
     def extract_host(self, vol, params):
         """vol: mha.Volume in host memory.  Upload + extract (PCIe-inclusive)."""
         vox = np.ascontiguousarray(vol.voxels)
-        desc = make_desc(vox.dtype, vol.dims, vol.spacing, vol.origin, vol.direction)
+        desc = make_desc(vox.dtype, vol.dims, vol.spacing, vol.origin, vol.direction, getattr(vol, "index_start", (0, 0, 0)))
         check_iso(int(desc.pixel_type), params)
         res = _abi.Result()
         _abi.check(self._ctx, self._lib.cuberille_extract_host(
@@ -488,7 +489,7 @@ class CuberilleImageToMeshFilter:
         self._dtype = image.voxels.dtype
         self._threshold = _clamp(self._threshold_asked, 0.0, _pixel_max(self._dtype))
         if self._acquire(False) and self._dtype in PIXEL_CODES:
-            self._extractor.warm_up(make_desc(self._dtype, image.dims, image.spacing, image.origin, image.direction))
+            self._extractor.warm_up(make_desc(self._dtype, image.dims, image.spacing, image.origin, image.direction, image.index_start))
 
     # h:180-181
     def SetIsoSurfaceValue(self, v):

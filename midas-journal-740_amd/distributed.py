@@ -348,7 +348,7 @@ class ShardedExtractor:
     def __init__(self, extractor, global_dims, np_dtype, rank, world, group=None, spacing=(1.0, 1.0, 1.0),
                  origin=(0.0, 0.0, 0.0), direction=None, check_aliasing=True, params=None, halo=None,
                  cross_slab_aliasing=True, thin_halo=False, guard=1, device_offsets=True, bounds=None, close_steps=False,
-                 bits_first=False, step_timeout=None, abort_on_timeout=False):
+                 bits_first=False, step_timeout=None, abort_on_timeout=False, index_start=(0, 0, 0)):
         """params: the extraction parameters the slabs will be used with -- the halo is sized for them
         (cuberille_required_halo); without them it is the HALO of the default parameters on unit spacing.
         check_aliasing: look for quirk Q1 (vertex re-use across a run of empty slices) crossing a slab boundary -- costs
@@ -387,7 +387,7 @@ class ShardedExtractor:
             raise ValueError("bounds must cut slices 0 .. %d into %d contiguous, non-empty slabs" % (self.nz, world))
         self.z0, self.z1 = self.bounds[rank]
         self._geo = (np_dtype, spacing, origin, direction)
-        whole = make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction)
+        whole = make_desc(np_dtype, (self.nx, self.ny, self.nz), spacing, origin, direction, index_start)
         if halo is None:
             halo = HALO
             if params is not None:
@@ -396,7 +396,7 @@ class ShardedExtractor:
         self.lo, self.hi = buffer_range(self.nz, self.z0, self.z1, self.halo)
         if world > self.nz:
             raise ValueError("more ranks (%d) than slices (%d)" % (world, self.nz))
-        self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction)
+        self.desc = make_desc(np_dtype, (self.nx, self.ny, self.hi - self.lo), spacing, origin, direction, index_start)
         self.slab = _abi.Slab(self.nz, self.lo, self.z0, self.z1, 0, 0, None, None)
         # the thin form of the same slab: a window of the same buffer
         self.thin = None
@@ -408,7 +408,7 @@ class ShardedExtractor:
             if t[0] < self.halo or t[1] < self.halo:          # (else there is nothing to save)
                 self.thin = t
                 self.tlo, self.thi = buffer_range(self.nz, self.z0, self.z1, t)
-                self.thin_desc = make_desc(np_dtype, (self.nx, self.ny, self.thi - self.tlo), spacing, origin, direction)
+                self.thin_desc = make_desc(np_dtype, (self.nx, self.ny, self.thi - self.tlo), spacing, origin, direction, index_start)
                 self.thin_slab = _abi.Slab(self.nz, self.tlo, self.z0, self.z1, 0, _abi.SLAB_THIN_HALO, None, None)
         self.itemsize = int(np.dtype(np_dtype).itemsize)
         self._halo_event = None

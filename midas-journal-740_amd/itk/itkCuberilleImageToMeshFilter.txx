@@ -245,21 +245,21 @@ void FillCells(TMesh *mesh, const uint64_t *ids, uint64_t nCells, FillTag<true>)
   EncapsulateMetaData<typename CellSlab<TCell>::Pointer>(mesh->GetMetaDataDictionary(), std::string("CuberilleCellSlab"), holder);
 }
 
-// the image as the C ABI takes it (itk::Image::{GetBufferedRegion, GetSpacing, GetDirection} and the physical position of
-// the first buffered pixel: txx:71-99,266-270); false when nothing is buffered yet
+// the image as the C ABI takes it: itk::Image::{GetBufferedRegion, GetSpacing, GetOrigin, GetDirection} (txx:71-99,266-270),
+// the region's start index handed over as it is -- the library applies ITK's index <-> point transforms to buffer position +
+// start index, like ITK itself (a cropped image keeps the index it was cut at); false when nothing is buffered yet
 template <class TImage> bool DescribeImage(const TImage *image, cuberille_image_desc &desc)
 {
   desc.pixel_type = PixelCode<typename TImage::PixelType>::Value;
   if (!image || TImage::ImageDimension != 3) return false;
   const typename TImage::RegionType region = image->GetBufferedRegion();
-  typename TImage::PointType firstPixel;
-  image->TransformIndexToPhysicalPoint(region.GetIndex(), firstPixel);   // buffered index 0 of the C ABI
   bool any = true;
   for (unsigned int i = 0; i < 3; i++)
     {
     desc.dims[i] = static_cast<int64_t>(region.GetSize()[i]);
     desc.spacing[i] = image->GetSpacing()[i];
-    desc.origin[i] = firstPixel[i];
+    desc.origin[i] = image->GetOrigin()[i];
+    desc.index_start[i] = static_cast<int64_t>(region.GetIndex()[i]);
     for (unsigned int j = 0; j < 3; j++) desc.direction[i * 3 + j] = image->GetDirection()[i][j];
     if (desc.dims[i] < 1) any = false;
     }

@@ -376,11 +376,65 @@ static bool stale_gradient_switch(const char *vtkName)
   return ok;
 }
 
+// A buffered region that does not start at index 0 (what a crop or a paste leaves behind): the filter hands ITK's own origin and
+// the region's start index to the library (cuberille_image_desc::index_start) instead of moving the origin.  With unit spacing
+// and integral origins both descriptions are exact: the mesh of an image whose region starts at (5, -3, 100) equals, bit for
+// bit, the mesh of the same pixels in a region at 0 with the origin moved by as much.
+static bool region_index_matches_moved_origin()
+{
+  typedef itk::Image<float, 3> ImageType;
+  typedef itk::Mesh<float, 3> MeshType;
+  typedef itk::CuberilleImageToMeshFilter<ImageType, MeshType> FilterType;
+  const int n = 24;
+  const long off[3] = {5, -3, 100};
+  ImageType::Pointer img[2] = {ImageType::New(), ImageType::New()};
+  for (int v = 0; v < 2; v++)
+    {
+    ImageType::RegionType region;
+    ImageType::IndexType start;
+    ImageType::SizeType size;
+    ImageType::PointType origin;
+    for (int k = 0; k < 3; k++) { start[k] = v ? off[k] : 0; origin[k] = v ? 2.0 : 2.0 + off[k]; }
+    size.Fill(n);
+    region.SetIndex(start);
+    region.SetSize(size);
+    img[v]->SetRegions(region);
+    img[v]->SetOrigin(origin);
+    img[v]->Allocate();
+    for (int z = 0; z < n; z++)
+      for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+          {
+          ImageType::IndexType idx;
+          idx[0] = x + start[0]; idx[1] = y + start[1]; idx[2] = z + start[2];
+          const double r = std::sqrt((x - 11.3) * (x - 11.3) + (y - 11.6) * (y - 11.6) + (z - 11.1) * (z - 11.1));
+          img[v]->SetPixel(idx, static_cast<float>(8.0 - r + 0.03125 * ((x * 7 + y * 13 + z * 5) % 11)));
+          }
+    }
+  std::vector<float> pts[2];
+  unsigned long cells[2];
+  for (int v = 0; v < 2; v++)
+    {
+    FilterType::Pointer f = FilterType::New();
+    f->SetInput(img[v]);
+    f->SetIsoSurfaceValue(0.0f);
+    f->SetProjectVertexSurfaceDistanceThreshold(0.01);
+    f->SetProjectVertexStepLength(0.25);
+    f->Update();
+    pts[v] = flat_points(f->GetOutput());
+    cells[v] = f->GetOutput()->GetNumberOfCells();
+    }
+  const bool ok = pts[0].size() == pts[1].size() && cells[0] == cells[1] && cells[0] > 0 && differing_points(pts[0], pts[1]) == 0;
+  std::cout << "region-index " << pts[1].size() / 3 << " " << cells[1] << (ok ? " same" : " DIFFERENT") << std::endl;
+  return ok;
+}
+
 int main(int argc, char **argv)
 {
   try
     {
     bool ok = true;
+    ok &= region_index_matches_moved_origin();
     ok &= stale_gradient_switch(argc > 1 ? argv[1] : 0);
     ok &= mesh_outlives_the_filter();
     ok &= dynamic_traits_mesh_equals_static();

@@ -20,7 +20,9 @@ _ELEMENT_NAMES = {np.dtype(v): k for k, v in _ELEMENT_TYPES.items()}
 class Volume:
     """A 3-D image: voxels[z, y, x] plus ITK-style geometry."""
 
-    def __init__(self, voxels, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None):
+    def __init__(self, voxels, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=None, index_start=(0, 0, 0)):
+        # index_start: (x, y, z) ITK index of voxels[0, 0, 0] -- GetBufferedRegion().GetIndex(); 0 for an image read from a file
+        self.index_start = tuple(int(v) for v in index_start)
         self.voxels = np.ascontiguousarray(voxels)
         self.spacing = tuple(float(s) for s in spacing)
         self.origin = tuple(float(o) for o in origin)

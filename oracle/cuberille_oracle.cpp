@@ -38,6 +38,8 @@ typedef int64_t idx_t;
 
 struct Geometry {
   idx_t n[3];
+  idx_t start[3];  // index of the first buffered pixel (ImageRegion::GetIndex): ITK's transforms and interpolators work on
+                   // INDICES, buffer position + start; everything below takes and returns buffer positions
   double spacing[3], origin[3], dir[9];
   double i2p[9];   // Direction * diag(spacing)           (ImageBase::m_IndexToPhysicalPoint)
   double p2i[9];   // inverse of i2p                      (ImageBase::m_PhysicalPointToIndex)
@@ -67,6 +69,7 @@ Geometry make_geometry(const oracle_image *img) {
   Geometry g;
   for (int i = 0; i < 3; i++) {
     g.n[i] = img->dims[i];
+    g.start[i] = img->index_start[i];
     g.spacing[i] = img->spacing[i];
     g.origin[i] = img->origin[i];
   }
@@ -104,7 +107,7 @@ struct Image {
 void index_to_point(const Geometry &g, const idx_t idx[3], float p[3]) {
   for (int r = 0; r < 3; r++) {
     double sum = 0.0;
-    for (int c = 0; c < 3; c++) sum += g.i2p[r * 3 + c] * (double)idx[c];
+    for (int c = 0; c < 3; c++) sum += g.i2p[r * 3 + c] * (double)(idx[c] + g.start[c]);
     p[r] = (float)(sum + g.origin[r]);
   }
 }
@@ -130,8 +133,9 @@ inline void make_cell(const Geometry &g, const double ci[3], Cell8 &c) {
   for (int k = 0; k < 3; k++) {
     const double b = std::floor(ci[k]);
     c.d[k] = ci[k] - b;
-    c.lo[k] = to_index_clamped(b, g.n[k] - 1);
-    c.hi[k] = to_index_clamped(b + 1.0, g.n[k] - 1);
+    // (the neighbours clamp into [StartIndex, EndIndex] of the buffered region; stored as buffer positions)
+    c.lo[k] = to_index_clamped(b - (double)g.start[k], g.n[k] - 1);
+    c.hi[k] = to_index_clamped(b + 1.0 - (double)g.start[k], g.n[k] - 1);
   }
 }
 
@@ -750,6 +754,7 @@ bool valid_image(const oracle_image *img) {
   if (!img || !img->voxels) return false;
   if (img->pixel_type < 0 || img->pixel_type > ORACLE_PIX_U64) return false;
   for (int i = 0; i < 3; i++) if (img->dims[i] < 1 || !(img->spacing[i] > 0.0)) return false;
+  for (int i = 0; i < 3; i++) if (img->index_start[i] < -(1LL << 30) || img->index_start[i] > (1LL << 30)) return false;
   return true;
 }
 

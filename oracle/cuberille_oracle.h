@@ -40,6 +40,8 @@ typedef struct {
   double origin[3];
   double direction[9];    /* row-major 3x3 */
   const void *voxels;     /* host pointer, Nx*Ny*Nz pixels */
+  int64_t index_start[3]; /* itk::ImageRegion::GetIndex() of the buffered region: pixel (i,j,k) of the buffer is INDEX (i,j,k) +
+                             index_start to TransformIndexToPhysicalPoint (txx:266) and to the interpolators (txx:451,455) */
 } oracle_image;
 
 typedef struct {

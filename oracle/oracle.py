@@ -23,7 +23,8 @@ PIXEL_CODES = {
 
 class _Image(C.Structure):
     _fields_ = [("pixel_type", C.c_int32), ("dims", C.c_int64 * 3), ("spacing", C.c_double * 3),
-                ("origin", C.c_double * 3), ("direction", C.c_double * 9), ("voxels", C.c_void_p)]
+                ("origin", C.c_double * 3), ("direction", C.c_double * 9), ("voxels", C.c_void_p),
+                ("index_start", C.c_int64 * 3)]
 
 
 class _Params(C.Structure):
@@ -70,7 +71,7 @@ def lib():
     return _lib
 
 
-def _image(vol, spacing, origin, direction):
+def _image(vol, spacing, origin, direction, index_start=(0, 0, 0)):
     vol = np.ascontiguousarray(vol)
     assert vol.ndim == 3, "volume is indexed [z, y, x]"
     img = _Image()
@@ -81,6 +82,7 @@ def _image(vol, spacing, origin, direction):
     img.origin[:] = list(origin)
     img.direction[:] = list(np.asarray(direction, dtype=np.float64).reshape(9))
     img.voxels = vol.ctypes.data
+    img.index_start[:] = [int(v) for v in index_start]
     return img, vol
 
 
@@ -93,13 +95,13 @@ class OracleMesh:
 
 def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=0.95, max_steps=50,
         spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), gradient_threads=1,
-        faithful_cells=False, variant=0, gradient=0, first=None):
+        faithful_cells=False, variant=0, gradient=0, first=None, index_start=(0, 0, 0)):
     """Run the restated reference sweep on `vol` ([z,y,x] numpy array).  first: None, or the input of the filter object's
     FIRST projecting Update() as (vol, spacing, origin, direction) -- quirk Q3 (txx:484): this update then walks along
     that image's gradient.  variant: 0 the default projection,
     1 / 2 the reference's compiled-out USE_ADVANCED_PROJECTION / USE_LINESEARCH_PROJECTION branches.  gradient: 0 the
     central differences of itk::GradientImageFilter, 1 USE_GRADIENT_RECURSIVE_GAUSSIAN (compiled out upstream too)."""
-    img, keep = _image(vol, spacing, origin, direction)
+    img, keep = _image(vol, spacing, origin, direction, index_start)
     # 64-bit integer pixels: the iso value as the C cast of the reference takes it (h:180-181), truncated toward zero
     try:
         iso_int = int(iso) if isinstance(iso, (int, np.integer)) else math.trunc(float(iso))
@@ -115,7 +117,7 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     mesh = _Mesh()
     if first is not None:
         fvol, *fgeo = first if isinstance(first, (tuple, list)) else (first,)
-        fgeo = list(fgeo) + [(1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3)][len(fgeo):]
+        fgeo = list(fgeo) + [(1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3), (0, 0, 0)][len(fgeo):]
         fimg, fkeep = _image(np.asarray(fvol), *fgeo)
         rc = lib().cuberille_oracle_run_after(C.byref(img), C.byref(fimg), C.byref(prm), C.byref(mesh))
         del fkeep
@@ -136,8 +138,8 @@ def run(vol, iso, triangles=True, project=True, threshold=0.5, step=-1.0, relax=
     return OracleMesh(pts, cells, info)
 
 
-def interpolate(vol, point, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3)):
-    img, keep = _image(vol, spacing, origin, direction)
+def interpolate(vol, point, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), index_start=(0, 0, 0)):
+    img, keep = _image(vol, spacing, origin, direction, index_start)
     p = (C.c_double * 3)(*point)
     return lib().cuberille_oracle_interpolate(C.byref(img), p)
 
@@ -150,8 +152,9 @@ def gradient_at_index(vol, idx, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0),
     return np.array(list(g), dtype=np.float32)
 
 
-def index_to_point(vol, idx, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3)):
-    img, keep = _image(vol, spacing, origin, direction)
+def index_to_point(vol, idx, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), index_start=(0, 0, 0)):
+    """idx: the pixel's position in the buffer ([x, y, z]); its ITK index is idx + index_start."""
+    img, keep = _image(vol, spacing, origin, direction, index_start)
     i = (C.c_int64 * 3)(*idx)
     p = (C.c_float * 3)()
     lib().cuberille_oracle_index_to_point(C.byref(img), i, p)

@@ -138,6 +138,8 @@ def main():
             dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
             vox, iso = draw_field(rng, (nz, ny, nx), dt)
             spacing, origin, direction = draw_geometry(rng)
+            # the buffered region's start index (a cropped image keeps the index it was cut at)
+            start = tuple(int(v) for v in rng.integers(-3000, 3000, size=3)) if rng.random() < 0.3 else (0, 0, 0)
             project = bool(rng.random() < 0.75)
             variant = int(rng.choice([0, 0, 0, 1, 2])) if project else 0
             kw = dict(triangles=bool(rng.integers(0, 2)), project=project,
@@ -147,12 +149,12 @@ def main():
             route = str(rng.choice(["host", "device", "stream", "slabs", "thin_slabs", "count_emit", "held", "switch"]))
             if args.recursive_gaussian and project and min(nx, ny, nz) >= 4 and route in ("host", "device", "stream", "count_emit", "switch"):
                 kw["gradient"] = 1                         # USE_GRADIENT_RECURSIVE_GAUSSIAN (whole volumes, four voxels along every axis)
-            vol = pkg.Volume(vox, spacing=spacing, origin=origin, direction=direction)
-            okw = dict(kw, spacing=spacing, origin=origin, direction=direction)
+            vol = pkg.Volume(vox, spacing=spacing, origin=origin, direction=direction, index_start=start)
+            okw = dict(kw, spacing=spacing, origin=origin, direction=direction, index_start=start)
             recipe = dict(case=case, seed=args.seed, shape=[nz, ny, nx], dtype=np.dtype(dt).name, iso=iso, route=route, kw=kw,
-                          spacing=spacing, origin=origin, direction=direction.tolist())
+                          spacing=spacing, origin=origin, direction=direction.tolist(), index_start=start)
             prm = pkg.make_params(iso, **kw)
-            desc = pkg.make_desc(vox.dtype, (nx, ny, nz), spacing, origin, direction)
+            desc = pkg.make_desc(vox.dtype, (nx, ny, nz), spacing, origin, direction, start)
             try:
                 ref = None
                 if route == "host":
@@ -191,16 +193,17 @@ def main():
                     fshape = (int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.choice([3, 17, 64, 70])))
                     fvox, _ = draw_field(rng, fshape, dt)
                     fs, fo, fd = draw_geometry(rng)
+                    fstart = tuple(int(v) for v in rng.integers(-100, 100, size=3)) if rng.random() < 0.3 else (0, 0, 0)
                     held.hold_gradient(False)
                     held.hold_gradient(True)
                     if not project:
                         kw["project"] = okw["project"] = True
                         prm = pkg.make_params(iso, **kw)
-                    held.extract_host(pkg.Volume(fvox, spacing=fs, origin=fo, direction=fd), prm)
+                    held.extract_host(pkg.Volume(fvox, spacing=fs, origin=fo, direction=fd, index_start=fstart), prm)
                     held.extract_host(vol, prm)
                     mesh = held.download()
-                    recipe["first"] = dict(shape=list(fshape), spacing=fs, origin=fo, direction=fd.tolist())
-                    ref = oracle.run(vox, iso, first=(fvox, fs, fo, fd), **okw)
+                    recipe["first"] = dict(shape=list(fshape), spacing=fs, origin=fo, direction=fd.tolist(), index_start=fstart)
+                    ref = oracle.run(vox, iso, first=(fvox, fs, fo, fd, fstart), **okw)
                 else:   # slabs stitched by hand: counts, id offsets, concatenation; thin: 3 + 3 halo slices, escaped walks again
                     thin = route == "thin_slabs"
                     occupied = True
@@ -222,7 +225,7 @@ def main():
                         for a, b in zip(cuts[:-1], cuts[1:]):
                             lo, hi = (max(a - tb - 1, 0), min(b + ta + 1, nz)) if thin else (max(a - below, 0), min(b + above, nz))
                             dev = to_device(torch, vox[lo:hi])
-                            sdesc = pkg.make_desc(vox.dtype, (nx, ny, hi - lo), spacing, origin, direction)
+                            sdesc = pkg.make_desc(vox.dtype, (nx, ny, hi - lo), spacing, origin, direction, start)
                             n_p, n_c = ex.count(dev.data_ptr(), sdesc, prm, pkg._abi.Slab(nz, lo, a, b, 0, pkg._abi.SLAB_THIN_HALO if thin else 0))
                             if thin:
                                 ex.emit_points()

@@ -80,6 +80,10 @@ def test_cxx_dropin_instantiates_for_other_pixel_types(oracle, tmp_path):
     stale = [l for l in lines if l.startswith("stale-gradient")]
     assert len(stale) == 1 and stale[0].endswith(" consistent") and int(stale[0].split()[4]) > 0, stale
     lines = [l for l in lines if not l.startswith("stale-gradient")]
+    # (ABI 13: a buffered region that starts at a non-zero index goes to the library as it is)
+    reg = [l for l in lines if l.startswith("region-index")]
+    assert len(reg) == 1 and reg[0].endswith(" same"), reg
+    lines = [l for l in lines if not l.startswith("region-index")]
 
     def stale_field(nx, ny, nz, cx, radius):
         z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
@@ -628,3 +632,53 @@ def test_hold_gradient_across_geometries_and_sizes(pkg, oracle):
     f.SetReproduceStaleGradient(False)
     f.Update()
     assert_same_mesh(f.GetOutput(), oracle.run(later[0].voxels, 0.0, **kw))
+
+
+def test_buffered_region_start_index_matches_oracle(pkg, oracle, extractor):
+    """cuberille_image_desc::index_start (ABI 13): a region that starts at a non-zero ITK index (a cropped image) goes through the
+    index <-> point transforms and the interpolators as buffer position + start, like ITK -- host upload, resident volume, slabs and
+    a held gradient against the oracle with the same start; a start outside +-2^30 is refused."""
+    import torch
+    c, s_ = np.cos(0.37), np.sin(0.37)
+    d = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    z, y, x = np.meshgrid(np.arange(30.0), np.arange(26.0), np.arange(70.0), indexing="ij")
+    vox = (9.0 - np.sqrt((x - 33.3) ** 2 * 0.2 + (y - 12.5) ** 2 + (z - 14.2) ** 2) + 0.4 * np.sin(0.8 * x) * np.cos(0.6 * y + 0.3 * z)).astype(np.float32)
+    nz, ny, nx = vox.shape
+    for geo in (dict(spacing=(0.7, 1.3, 0.9), origin=(3.3, -2.1, 0.77), direction=d, index_start=(1000, -37, 512)),
+                dict(spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=np.eye(3), index_start=(-5, 7, 123456)),
+                dict(spacing=(2.0, 0.5, 1.0), origin=(1e6, -3.0, 0.25), direction=d.T, index_start=(0, 0, -999))):
+        kw = dict(triangles=1, project=1, threshold=0.01, step=0.2 * min(geo["spacing"]), relax=0.9, max_steps=20)
+        ref = oracle.run(vox, 0.0, **geo, **kw)
+        prm = pkg.make_params(0.0, **kw)
+        extractor.extract_host(pkg.Volume(vox, **geo), prm)
+        assert_same_mesh(extractor.download(), ref)
+        dev = torch.from_numpy(vox).cuda()
+        extractor.extract_device(dev.data_ptr(), pkg.make_desc(np.float32, (nx, ny, nz), **geo), prm)
+        assert_same_mesh(extractor.download(), ref)
+        below, above = pkg.required_halo(pkg.make_desc(np.float32, (nx, ny, nz), **geo), prm)
+        pts, cells, poff = [], [], 0
+        for a, b in [(0, 11), (11, 12), (12, 30)]:
+            lo, hi = max(a - below, 0), min(b + above, nz)
+            n_p, _ = extractor.count(dev[lo:hi].data_ptr(), pkg.make_desc(np.float32, (nx, ny, hi - lo), **geo), prm, pkg._abi.Slab(nz, lo, a, b, 0, 0))
+            extractor.emit(poff)
+            m = extractor.download()
+            pts.append(m.points)
+            cells.append(m.cells)
+            poff += n_p
+        assert_same_mesh(pkg.Mesh(np.concatenate(pts), np.concatenate(cells)), ref)
+    # a held gradient keeps the first volume's start index with its geometry
+    first = dict(spacing=(1.1, 0.9, 1.0), origin=(2.0, 2.0, -1.0), direction=d, index_start=(40, -2, 9))
+    later = dict(spacing=(1.0, 1.0, 1.0), origin=(0.5, 0.0, 0.0), direction=np.eye(3), index_start=(3, 3, 3))
+    kw = dict(triangles=1, project=1, threshold=0.01, step=0.2, relax=0.9, max_steps=20)
+    ex = pkg.Extractor(0)
+    try:
+        ex.hold_gradient(True)
+        ex.extract_host(pkg.Volume(vox[:20, :20, :40], **first), pkg.make_params(0.0, **kw))
+        ex.extract_host(pkg.Volume(vox, **later), pkg.make_params(0.0, **kw))
+        assert_same_mesh(ex.download(), oracle.run(vox, 0.0, first=(vox[:20, :20, :40], first["spacing"], first["origin"], first["direction"],
+                                                                    first["index_start"]), **later, **kw))
+    finally:
+        ex.close()
+    with pytest.raises(pkg._abi.CuberilleError) as e:
+        extractor.extract_host(pkg.Volume(vox, index_start=(0, 0, 1 << 31)), pkg.make_params(0.0))
+    assert e.value.code == pkg._abi.ERR_LIMIT

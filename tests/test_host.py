@@ -23,11 +23,11 @@ def test_library_builds_and_exports_the_whole_header(pkg):
     assert declared == set(pkg._abi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 12
+    assert lib.cuberille_abi_version() == pkg._abi.ABI_VERSION == 13
 
 
 def test_struct_layouts_match_the_header(pkg):
-    assert C.sizeof(pkg._abi.ImageDesc) == 8 + 24 + 24 + 24 + 72
+    assert C.sizeof(pkg._abi.ImageDesc) == 8 + 24 + 24 + 24 + 72 + 24      # (+ index_start, ABI 13)
     assert C.sizeof(pkg._abi.Params) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert C.sizeof(pkg._abi.Slab) == 64
     assert C.sizeof(pkg._abi.SlabStatus) == 40

@@ -367,6 +367,40 @@ def test_second_update_walks_along_the_first_inputs_gradient(oracle):
         assert np.array_equal(a.cells, b.cells) and not np.array_equal(a.points, b.points), extra
 
 
+def test_buffered_region_start_index(oracle):
+    """A buffered region that does not start at index 0 (a cropped or pasted itk::Image): TransformIndexToPhysicalPoint (txx:266)
+    and the interpolators (txx:451,455) work on INDICES, buffer position + start.  With arithmetic that is exact either way
+    (spacings that are powers of two, origins on their grid) the mesh equals, bit for bit, the mesh of the same pixels described
+    with start 0 and the origin moved to the first buffered pixel; index_to_point is the transform of position + start; with
+    awkward geometry the two descriptions still give the same mesh up to the last bits of the doubles involved."""
+    vol = _small_field()
+    kw = dict(threshold=0.01, step=0.125, relax=0.9, max_steps=14)
+    spacing, origin, start = (0.5, 2.0, 1.0), (4.5, -6.0, 3.0), (1000, -37, 512)
+    moved = tuple(origin[k] + spacing[k] * start[k] for k in range(3))              # exact
+    for tri in (False, True):
+        a = oracle.run(vol, 0.0, triangles=tri, spacing=spacing, origin=origin, index_start=start, **kw)
+        b = oracle.run(vol, 0.0, triangles=tri, spacing=spacing, origin=moved, **kw)
+        assert np.array_equal(a.cells, b.cells) and np.array_equal(a.points.view(np.uint32), b.points.view(np.uint32))
+        assert a.info["proj_iterations"] == b.info["proj_iterations"]
+    p = oracle.index_to_point(vol, (3, 4, 5), spacing=spacing, origin=origin, index_start=start)
+    assert np.array_equal(p, np.array([origin[k] + spacing[k] * ((3, 4, 5)[k] + start[k]) for k in range(3)], dtype=np.float32))
+    # interpolation at a point: the same pixel values whichever way the region is described
+    q = tuple(moved[k] + spacing[k] * (2.25, 3.5, 4.75)[k] for k in range(3))
+    assert oracle.interpolate(vol, q, spacing=spacing, origin=origin, index_start=start) == oracle.interpolate(vol, q, spacing=spacing, origin=moved)
+    # ... and outside the region the neighbours clamp to ITS ends, not to index 0
+    far = tuple(moved[k] - 5.0 * spacing[k] for k in range(3))
+    assert oracle.interpolate(vol, far, spacing=spacing, origin=origin, index_start=start) == float(vol[0, 0, 0])
+    # awkward geometry: a rotation, spacings and origins that round -- equal to a relative 1e-6 (mostly to the bit)
+    c, s_ = np.cos(0.37), np.sin(0.37)
+    d = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    spacing, origin = (0.7, 1.3, 0.9), (3.3, -2.1, 0.77)
+    moved = tuple(np.asarray(origin) + (d @ np.diag(spacing)) @ np.asarray(start, dtype=np.float64))
+    a = oracle.run(vol, 0.0, spacing=spacing, origin=origin, direction=d, index_start=start, **dict(kw, step=0.1))
+    b = oracle.run(vol, 0.0, spacing=spacing, origin=moved, direction=d, **dict(kw, step=0.1))
+    assert np.array_equal(a.cells, b.cells)
+    np.testing.assert_allclose(a.points, b.points, rtol=1e-5, atol=1e-4)
+
+
 def test_recursive_gaussian_gradient_against_second_restatement(oracle):
     """USE_GRADIENT_RECURSIVE_GAUSSIAN (h:21,163-164; txx:488-491), compiled out upstream and with no fixture: the
     oracle's restatement of ITK's recursive Gaussian gradient + the walk through it against a second restatement in
