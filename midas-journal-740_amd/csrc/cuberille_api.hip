@@ -356,7 +356,6 @@ void resolve(const cuberille_image_desc *img, const cuberille_params *prm, Geo &
     geo.origin[i] = img->origin[i];
     geo.gcoef[i] = (float)(0.5 * (1.0 / img->spacing[i]));
     geo.istart[i] = (int)img->index_start[i];
-    geo.start[i] = (double)img->index_start[i];
     if (img->spacing[i] > maxSpacing) maxSpacing = img->spacing[i];
   }
   for (int i = 0; i < 9; i++) geo.dir[i] = img->direction[i];
@@ -1522,7 +1521,7 @@ int cuberille_slab_info(cuberille_ctx *c, cuberille_slab_status *out) {
 static bool set_opt(Tuning &t, const char *name, long long v) {
 #define OPT(field) if (!std::strcmp(name, #field)) { t.field = (int)v; return true; }
   OPT(no_cmap) OPT(no_heads) OPT(no_vqueue) OPT(no_stream_classify) OPT(classify_variant) OPT(classify_grid)
-  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split) OPT(count_no_fold) OPT(proj_short)
+  OPT(points_variant) OPT(points_no_split) OPT(count_variant) OPT(cmap_linear) OPT(proj_chunk) OPT(proj_waves) OPT(proj_refill) OPT(proj_xcd) OPT(proj_literal) OPT(stage_timing) OPT(classify_keep_tail) OPT(proj_chunk64_below) OPT(points_split) OPT(count_no_fold) OPT(proj_short) OPT(proj_ident)
 #undef OPT
   return false;
 }

@@ -23,7 +23,8 @@ struct Geo {
   double dir[9];
   float gcoef[3];     // derivative tap coefficient per axis: float(0.5 * (1/spacing))
   int istart[3];      // index of the first buffered pixel (itk::ImageRegion::GetIndex): ITK's index <-> point transforms and
-  double start[3];    // its interpolators work on INDICES = buffer position + start (the same integers, as int and double)
+                      // its interpolators work on INDICES = position + start.  (Only these three scalars: the walk kernel
+                      // keeps the whole struct in SGPRs and spills what does not fit into its hot loop.)
 };
 
 // Layout of the packed inside-bit volume and of the slab being processed.
@@ -161,6 +162,7 @@ struct Tuning {
   // per vertex), XCD-contiguous batches, the reference's interpolation loop to the letter on every pass
   // (proj_waves 0: 16 384, or 65 536 waves dealing batches of 64 where walks are short -- see launch_project)
   int proj_chunk = 0, proj_waves = 0, proj_refill = 0, proj_xcd = 0, proj_literal = 0;
+  int proj_ident = -1;        // 1 / 0: the walk kernel specialised for identity geometry where the geometry allows / never (A/B); -1: the default
   int proj_short = -1;        // the launch shapes of SHORT walks (1) or of long ones (0); -1: by the previous extraction's passes per vertex
   int count_no_fold = 0;      // 1: the block scan always as a launch of its own (A/B of the scan folded into small count launches)
   int stage_timing = 0;       // 1: events between the stages too (cuberille_result::ms_classify ... ms_emit_cells)

@@ -1802,8 +1802,9 @@ __device__ __forceinline__ int getbit(const u64 *__restrict__ bits, const Grid &
 
 // I3 + txx:268-270: lattice corner -> physical point - spacing/2, in the mesh's float coordinates
 __device__ __forceinline__ void corner_point(const Geo &geo, long long cx, long long cy, long long cz, float p[3]) {
-  // (cx, cy, cz: positions in the volume; TransformIndexToPhysicalPoint takes the INDEX, position + region start)
-  const double idx[3] = {(double)cx + geo.start[0], (double)cy + geo.start[1], (double)cz + geo.start[2]};
+  // (cx, cy, cz: positions in the volume; TransformIndexToPhysicalPoint takes the INDEX, position + region start -- both within
+  //  2^31, cuberille_api.hip: validate -- added as integers, one conversion each)
+  const double idx[3] = {(double)((int)cx + geo.istart[0]), (double)((int)cy + geo.istart[1]), (double)((int)cz + geo.istart[2])};
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     double sum = 0.0;
@@ -2328,10 +2329,19 @@ struct Cell8 {
   double d[3];
 };
 
-__device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const int n[3], const double p[3], Cell8 &c) {
+__device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const int n[3], const double p[3], Cell8 &c,
+                                          bool diagP2I = false) {
   double cv[3], ci[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) cv[k] = p[k] - geo.origin[k];                // I4
+  if (diagP2I) {
+    // a diagonal PhysicalPointToIndex matrix (identity direction, any spacing): 0 + m*a + 0*b + 0*c is m*a + 0 while b and c
+    // are finite, and the zero's sign washes out as below; with a NaN or an infinity among b, c the full form makes ALL three
+    // indices NaN where this one keeps a's -- the same pass either way: one NaN weight factor makes all eight weights NaN,
+    // the value and the normal with them, and the vertex is NaN in every coordinate from then on
+#pragma unroll
+    for (int r = 0; r < 3; r++) ci[r] = geo.p2i[4 * r] * cv[r];
+  } else
   if (unitP2I) {
     // identity PhysicalPointToIndex matrix: 0 + 1*a + 0*b + 0*c is a + 0 for every a, b, c a vertex can hold
     // (finite or NaN), i.e. a itself except that -0 becomes +0 -- and ci is only used through floor(ci) and
@@ -2356,9 +2366,12 @@ __device__ __forceinline__ void make_cell(const Geo &geo, bool unitP2I, const in
     int bi;
     asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(bi) : "v"(b));
     const int end = n[k] - 1;
-    // (the interpolators clamp into [StartIndex, EndIndex] of the buffered region: as a position in the volume)
-    const int bc = min(max(bi - geo.istart[k], -1), end);
-    c.bc[k] = bc;
+    // (the interpolators clamp into [StartIndex, EndIndex] of the buffered region.  The cell is NAMED by its clamped INDEX --
+    //  the bounds are scalars, so a pass costs what it cost without a start index -- and only a gather turns that into
+    //  positions in the volume)
+    const int bcI = min(max(bi, geo.istart[k] - 1), end + geo.istart[k]);
+    c.bc[k] = bcI;
+    const int bc = bcI - geo.istart[k];
     c.lo[k] = max(bc, 0);
     c.hi[k] = min(bc + 1, end);
   }
@@ -2539,8 +2552,14 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // the escape list untouched and is walked again from its start once the deeper halo is there (MODE 2: the vertices
 // are taken from that list; `g` then describes the deeper buffer).  dyn (cuberille_step_begin): the launch was sized
 // blindly, the real counts are read from `tot`.
-template <class T, int MODE>
-__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentity,
+// GEOM 2 (IDENT): the PhysicalPointToIndex matrix and the direction matrix are both the identity and the buffered region starts at index 0
+// (unit spacing, no rotation, an image as read from a file -- every volume the reference ships and the bench's): their 39
+// scalars then never enter the kernel, which keeps its whole argument
+// block in SGPRs and spills what does not fit (62 of them before) into the lanes of a vector register its loop reads back.
+// GEOM 2 = that; 1: identity direction, region at 0, ANY spacing (a diagonal matrix: three scalars instead of eighteen -- the
+// anisotropic volumes of CT and MR); 0: anything (a rotation, a region that starts elsewhere).
+template <class T, int MODE, int GEOM>
+__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentityArg,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
                                                  int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
                                                  u32 *__restrict__ escList, u32 escCap, int dyn) {
@@ -2590,13 +2609,27 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   float vertex[3] = {0.f, 0.f, 0.f};
   double step = 0.0;
   unsigned numberOfSteps = 0;
-  int kc[3] = {-2, -2, -2};                        // cell held in registers, named by its clamped floor indices
+  constexpr int NO_CELL = -0x7fffffff - 1;         // (no clamped index is that low: start indices lie within +-2^30)
+  int kc[3] = {NO_CELL, NO_CELL, NO_CELL};         // cell held in registers, named by its clamped floor indices
   float G[8][3];
   typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
+  constexpr bool IDENT = GEOM == 2, DIAG = GEOM == 1;
   bool unitP2I = true;
+  if constexpr (GEOM == 0) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) unitP2I = unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
+    for (int i = 0; i < 9; i++) unitP2I = unitP2I && (geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0));
+  } else {
+    // (constants from here on: the rare paths that multiply by the matrices -- a non-finite tap -- read these, not the arguments)
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      geo.dir[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      if (IDENT || i % 4 != 0) geo.p2i[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    geo.istart[0] = geo.istart[1] = geo.istart[2] = 0;
+    unitP2I = IDENT;
+  }
+  const int dirIdentity = GEOM ? 1 : dirIdentityArg;
   for (;;) {
     const u64 idle = __ballot(!active);
     if (idle && next < end && (__popcll(idle) >= REFILL || idle == ~0ull)) {
@@ -2610,7 +2643,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
           vertex[0] = points[3 * idx]; vertex[1] = points[3 * idx + 1]; vertex[2] = points[3 * idx + 2];
           step = prm.step;
           numberOfSteps = 0;
-          kc[0] = -2;
+          kc[0] = NO_CELL;
           // (a ghost vertex on the ghost slice's BOTTOM plane was written as NaN by the point pass: no cell of this
           //  rank touches that plane, its position is the rank below's business)
           active = !(idx < nGhost && vertex[0] != vertex[0]);
@@ -2625,7 +2658,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
       bool done = false;
       const double p[3] = {(double)vertex[0], (double)vertex[1], (double)vertex[2]};
       Cell8 c;
-      make_cell(geo, unitP2I, n, p, c);
+      make_cell(geo, unitP2I, n, p, c, DIAG);
       if (MODE == 1 && (c.bc[0] != kc[0] || c.bc[1] != kc[1] || c.bc[2] != kc[2])) {
         // global slices the cell and its gradient ring read, against the buffer
         const int zlo = max(c.lo[2] - 1, 0), zhi = min(c.hi[2] + 1, n[2] - 1);
@@ -3563,13 +3596,26 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
     } else if (xcd == 0 && !shortWalks && blocks >= 1024 && (blocks < 2304 || blocks >= 8192)) {
       xcd = 32;
     } else if (xcd < 0) xcd = 0;
-#define CUBERILLE_LAUNCH_PROJECT(MODE)                                                                                       \
-    hipLaunchKernelGGL((k_project<T, MODE>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,        \
+    // the kernel's form by the geometry: 2 identity matrices and a region at index 0; 1 identity direction, any spacing (the
+    // inverse of a diagonal matrix by cofactors has exact zeros off its diagonal); 0 anything else
+    bool diag = dirIdentity != 0 && geo.istart[0] == 0 && geo.istart[1] == 0 && geo.istart[2] == 0 && tn.proj_ident != 0;
+    bool unit = diag;
+    for (int i = 0; i < 9; i++) {
+      if (i % 4 != 0) diag = diag && geo.p2i[i] == 0.0;
+      unit = unit && geo.p2i[i] == ((i % 4 == 0) ? 1.0 : 0.0);
+    }
+    const int geom = unit ? 2 : diag ? 1 : 0;
+#define CUBERILLE_LAUNCH_PROJECT(MODE, GEOM)                                                                                 \
+    hipLaunchKernelGGL((k_project<T, MODE, GEOM>), dim3(blocks), dim3(256), 0, s, (const T *)w.vox, g, geo, p, dirIdentity,  \
                        w.points, nPoints, nGhost, chunk, tn.proj_refill, xcd, tn.proj_literal, w.totals, w.escList,  \
                        w.escCap, dyn)
-    if (mode == 1) CUBERILLE_LAUNCH_PROJECT(1);
-    else if (mode == 2) CUBERILLE_LAUNCH_PROJECT(2);
-    else CUBERILLE_LAUNCH_PROJECT(0);
+#define CUBERILLE_LAUNCH_PROJECT_GEOM(MODE)                                                                                  \
+    do { if (geom == 2) CUBERILLE_LAUNCH_PROJECT(MODE, 2); else if (geom == 1) CUBERILLE_LAUNCH_PROJECT(MODE, 1);            \
+         else CUBERILLE_LAUNCH_PROJECT(MODE, 0); } while (0)
+    if (mode == 1) CUBERILLE_LAUNCH_PROJECT_GEOM(1);
+    else if (mode == 2) CUBERILLE_LAUNCH_PROJECT_GEOM(2);
+    else CUBERILLE_LAUNCH_PROJECT_GEOM(0);
+#undef CUBERILLE_LAUNCH_PROJECT_GEOM
 #undef CUBERILLE_LAUNCH_PROJECT
     return hipGetLastError();
   });
