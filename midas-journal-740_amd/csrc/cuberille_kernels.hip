@@ -2559,7 +2559,7 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // GEOM 2 = that; 1: identity direction, region at 0, ANY spacing (a diagonal matrix: three scalars instead of eighteen -- the
 // anisotropic volumes of CT and MR); 0: anything (a rotation, a region that starts elsewhere).
 template <class T, int MODE, int GEOM>
-__global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentityArg,
+__global__ __launch_bounds__(256, 3) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentityArg,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
                                                  int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
                                                  u32 *__restrict__ escList, u32 escCap, int dyn) {
@@ -2612,6 +2612,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
   constexpr int NO_CELL = -0x7fffffff - 1;         // (no clamped index is that low: start indices lie within +-2^30)
   int kc[3] = {NO_CELL, NO_CELL, NO_CELL};         // cell held in registers, named by its clamped floor indices
   float G[8][3];
+  double Gd[8][3];
   typename SiteValue<T>::type Vd[8];
   bool cellFinite = false;
   constexpr bool IDENT = GEOM == 2, DIAG = GEOM == 1;
@@ -2686,6 +2687,10 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         }
         cellFinite = (tf == 0.0f) && (td == 0.0);
         if (!cellFinite) gather_cell<T, true>(s, geo, dirIdentity != 0, c, G, Vd);   // rare: the reference's formula to the letter
+#pragma unroll
+        for (int counter = 0; counter < 8; counter++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) Gd[counter][k] = (double)G[counter][k];
       }
       // I7 (gradient, txx:451) and I5 (value, txx:455) share the cell and the weights.  The reference
       // loop skips zero weights and stops once the accumulated weight is exactly 1.  With finite
@@ -2714,7 +2719,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
 #pragma unroll
         for (int counter = 0; counter < 8; counter++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+          for (int k = 0; k < 3; k++) acc[k] += o[counter] * Gd[counter][k];
           value += o[counter] * (double)Vd[counter];
         }
       } else {
@@ -2723,7 +2728,7 @@ __global__ __launch_bounds__(256, 4) void k_project(const T *__restrict__ vox, G
         for (int counter = 0; counter < 8; counter++) {
           if (o[counter] != 0.0 && total != 1.0) {   // "if (overlap)" + "break once total == 1"
 #pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] += o[counter] * (double)G[counter][k];
+            for (int k = 0; k < 3; k++) acc[k] += o[counter] * Gd[counter][k];
             value += o[counter] * (double)Vd[counter];
             total += o[counter];
           }
@@ -3565,12 +3570,23 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   //  65 536 waves 4.14 against 4.30.  Below 4096 waves' worth of vertices the launch shapes of rounds 3-4 stand.)
   const bool shortWalks = tn.proj_short >= 0 ? tn.proj_short != 0 : tn.proj_refill >= 64;
   const u64 perWave = shortWalks ? 448 : 680;
+  constexpr u64 WALK_RESIDENT = 3072;       // waves of k_project the chip holds: 3 per SIMD (launch bounds), 1024 SIMDs
   u64 autoWaves = 16384;
   // (... in whole rounds of the 4096 waves the chip holds at 4 per SIMD: 4435 waves for the 3.0 M vertices of a 1000^3 sphere are
   //  one round and a tail of 339 waves that run alone -- 0.571 against 0.496 ms for 16 384)
-  if (shortWalks ? nPoints > 16384ull * perWave : nPoints >= 4096ull * perWave) autoWaves = ((nPoints / perWave + 4095) / 4096) * 4096;
+  if (shortWalks ? nPoints > 16384ull * perWave : nPoints > 16384ull * perWave)
+    autoWaves = ((nPoints / perWave + WALK_RESIDENT - 1) / WALK_RESIDENT) * WALK_RESIDENT;
+  else if (!shortWalks && nPoints >= WALK_RESIDENT * 64) {
+    // (a launch sized blindly is sized for a quarter more than the previous extraction's vertices: the rule goes by the expected number)
+    const u64 nExpected = dyn ? nPoints - nPoints / 5 : nPoints;
+    // (the kernel at 3 waves per SIMD -- gradients held as doubles -- re-swept, profiles/microbench/r5_walk_three_waves.log: whole
+    //  rounds of 3072 waves of ~300-520 vertices each, batches of 128 from 1.5 M vertices on: 0.8 / 1.8 / 2.8 / 3.2 / 6.3 M vertices
+    //  want 3072 / 6144 / 6144 / 6144 / 12 288 waves; the headline's 11.1 M stay with 16 384 -- 21 504 cost it 2.5 %)
+    autoWaves = ((nExpected / 520 + WALK_RESIDENT - 1) / WALK_RESIDENT) * WALK_RESIDENT;
+    if (autoWaves > 16384) autoWaves = 16384;
+  }
   const u64 gridWaves = tn.proj_waves > 0 ? (u64)tn.proj_waves : autoWaves;
-  const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : 8000000ull;
+  const u64 upTo = tn.proj_chunk64_below > 0 ? (u64)tn.proj_chunk64_below : (shortWalks ? 8000000ull : 1500000ull);
   u64 chunk = tn.proj_chunk > 0 ? (tn.proj_chunk < 64 ? 64 : (u64)tn.proj_chunk)
             : (nPoints <= 64ull * 4096 || (nPoints > 64 * gridWaves && (nPoints < upTo || shortWalks))) ? 64 : 128;
   while (chunk & (chunk - 1)) chunk &= chunk - 1;   // power of two (the kernel shifts instead of dividing)
