@@ -2559,7 +2559,7 @@ __device__ __forceinline__ void gather_cell(const Sampler<T> &s, const Geo &geo,
 // GEOM 2 = that; 1: identity direction, region at 0, ANY spacing (a diagonal matrix: three scalars instead of eighteen -- the
 // anisotropic volumes of CT and MR); 0: anything (a rotation, a region that starts elsewhere).
 template <class T, int MODE, int GEOM>
-__global__ __launch_bounds__(256, 3) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentityArg,
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4)) void k_project(const T *__restrict__ vox, Grid g, Geo geo, Params prm, int dirIdentityArg,
                                                  float *__restrict__ points, u64 nPoints, u64 nGhost, u64 chunk,
                                                  int REFILL, int xcdRemap, int forceLiteral, Totals *__restrict__ tot,
                                                  u32 *__restrict__ escList, u32 escCap, int dyn) {
@@ -2716,8 +2716,14 @@ __global__ __launch_bounds__(256, 3) void k_project(const T *__restrict__ vox, G
       literal |= !(o[7] > 1e-14);
       double acc[3] = {0.0, 0.0, 0.0}, value = 0.0;
       if (!literal) {
+        // (the first term of each sum is 0.0 + o*g: the product rounded once, and a -0 product made +0 -- which is fma(o, g, +0.0)
+        //  bit for bit, one instruction instead of two; the other seven terms stay a multiplication and an addition, rounded twice
+        //  like the reference's)
 #pragma unroll
-        for (int counter = 0; counter < 8; counter++) {
+        for (int k = 0; k < 3; k++) acc[k] = __builtin_fma(o[0], Gd[0][k], 0.0);
+        value = __builtin_fma(o[0], (double)Vd[0], 0.0);
+#pragma unroll
+        for (int counter = 1; counter < 8; counter++) {
 #pragma unroll
           for (int k = 0; k < 3; k++) acc[k] += o[counter] * Gd[counter][k];
           value += o[counter] * (double)Vd[counter];
@@ -2739,9 +2745,11 @@ __global__ __launch_bounds__(256, 3) void k_project(const T *__restrict__ vox, G
       if (!done) {
         // (the reference normalises before the test, txx:452; the normal is only used when stepping)
         float normal[3] = {(float)acc[0], (float)acc[1], (float)acc[2]};
-        double sq = 0.0;                                                      // I8
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double e = (double)normal[k]; sq += e * e; }
+        // I8: 0.0 + e0*e0 + e1*e1 + e2*e2 -- a square is never -0, so the leading 0.0 adds nothing
+        const double e0 = (double)normal[0], e1 = (double)normal[1], e2 = (double)normal[2];
+        double sq = e0 * e0;
+        sq += e1 * e1;
+        sq += e2 * e2;
         if (sq > 0.0 && sq < __builtin_inf()) {
           // sq is a sum of squares of floats, so it lies in [2^-298, 2^258): the compiler's f64 sqrt (rsq + the
           // refinement below, wrapped in a rescaling for arguments under 2^-767 and a pass-through for 0 and
@@ -2778,10 +2786,12 @@ __global__ __launch_bounds__(256, 3) void k_project(const T *__restrict__ vox, G
 #pragma unroll
           for (int k = 0; k < 3; k++) normal[k] = (float)((double)normal[k] / norm);
         }
-        const double sign = (value < iso) ? +1.0 : -1.0;                      // txx:463
+        // txx:463-467 (I9): normal * sign * step with sign = +-1 -- (n * +-1) * s and n * (+-s) are the same rounded product with the
+        // same sign, zeros included: one multiplication per axis instead of two
+        const double signedStep = (value < iso) ? step : -step;
 #pragma unroll
-        for (int k = 0; k < 3; k++)                                           // txx:464-467 (I9)
-          vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * sign * step));
+        for (int k = 0; k < 3; k++)
+          vertex[k] = (float)((double)vertex[k] + ((double)normal[k] * signedStep));
         step *= prm.relax;                                                    // txx:468
         done = numberOfSteps++ > prm.max_steps;                               // txx:469
         bySteps = done && idx >= nGhost;                                      // txx:470-472's counter
@@ -3570,7 +3580,7 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   //  65 536 waves 4.14 against 4.30.  Below 4096 waves' worth of vertices the launch shapes of rounds 3-4 stand.)
   const bool shortWalks = tn.proj_short >= 0 ? tn.proj_short != 0 : tn.proj_refill >= 64;
   const u64 perWave = shortWalks ? 448 : 680;
-  constexpr u64 WALK_RESIDENT = 3072;       // waves of k_project the chip holds: 3 per SIMD (launch bounds), 1024 SIMDs
+  constexpr u64 WALK_RESIDENT = 3072;       // the unit the sweeps below settled on for the wave count (the kernel holds 128 VGPRs: 4 waves per SIMD)
   u64 autoWaves = 16384;
   // (... in whole rounds of the 4096 waves the chip holds at 4 per SIMD: 4435 waves for the 3.0 M vertices of a 1000^3 sphere are
   //  one round and a tail of 339 waves that run alone -- 0.571 against 0.496 ms for 16 384)
@@ -3579,8 +3589,8 @@ hipError_t launch_project(int pixel_type, const Workspace &w, const Grid &g, con
   else if (!shortWalks && nPoints >= WALK_RESIDENT * 64) {
     // (a launch sized blindly is sized for a quarter more than the previous extraction's vertices: the rule goes by the expected number)
     const u64 nExpected = dyn ? nPoints - nPoints / 5 : nPoints;
-    // (the kernel at 3 waves per SIMD -- gradients held as doubles -- re-swept, profiles/microbench/r5_walk_three_waves.log: whole
-    //  rounds of 3072 waves of ~300-520 vertices each, batches of 128 from 1.5 M vertices on: 0.8 / 1.8 / 2.8 / 3.2 / 6.3 M vertices
+    // (the kernel with the gradients held as doubles, re-swept, profiles/microbench/r5_walk_three_waves.log: multiples
+    //  of 3072 waves of ~300-520 vertices each, batches of 128 from 1.5 M vertices on: 0.8 / 1.8 / 2.8 / 3.2 / 6.3 M vertices
     //  want 3072 / 6144 / 6144 / 6144 / 12 288 waves; the headline's 11.1 M stay with 16 384 -- 21 504 cost it 2.5 %)
     autoWaves = ((nExpected / 520 + WALK_RESIDENT - 1) / WALK_RESIDENT) * WALK_RESIDENT;
     if (autoWaves > 16384) autoWaves = 16384;
