@@ -117,6 +117,8 @@ def worker(rank, world, port, seconds, seed, out_path, replay=-1, start=0):
                 break
             err = None
             whole = None
+            sh = None
+            prm = None
             try:
                 prm = pkg.make_params(iso, **kw)
                 sh = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, spacing=spacing, origin=origin, direction=direction,
@@ -153,10 +155,11 @@ def worker(rank, world, port, seconds, seed, out_path, replay=-1, start=0):
             dist.all_reduce(flag)
             if int(flag[0]):
                 print(json.dumps({"FAILED": recipe, "rank": rank, "error": err, "counts": np.asarray(getattr(sh, "counts", [])).tolist(),
-                                  "stats": dict(sh.stats)}), flush=True)
+                                  "stats": dict(sh.stats) if sh is not None else None}), flush=True)
                 # the same case again on the same contexts (same history): a state left behind fails again, a race may not
-                for attempt in range(3):
+                for attempt in range(3 if prm is not None else 0):
                     verdict = "identical"
+                    sh2 = None
                     try:
                         sh2 = ShardedExtractor(ex, (nx, ny, nz), vox.dtype, rank, world, spacing=spacing, origin=origin, direction=direction,
                                                check_aliasing=True, params=prm, thin_halo="thin" in mode, device_offsets=mode.startswith("step"),
@@ -174,7 +177,8 @@ def worker(rank, world, port, seconds, seed, out_path, replay=-1, start=0):
                     except Exception as e2:  # noqa: BLE001
                         verdict = "RAISED %s: %s" % (type(e2).__name__, str(e2)[:200])
                     if rank == world - 1:
-                        print("again %d: %s counts %s stats %s" % (attempt, verdict, np.asarray(sh2.counts).tolist(), dict(sh2.stats)), flush=True)
+                        print("again %d: %s counts %s stats %s" % (attempt, verdict, np.asarray(getattr(sh2, "counts", [])).tolist(),
+                                                                    dict(sh2.stats) if sh2 is not None else None), flush=True)
                     dist.barrier()
                 rc = 1
                 break
