@@ -28,15 +28,17 @@ def main():
             cur[k] = v
     names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows),
                            capture_output=True, text=True).stdout.splitlines()
-    print("%-70s %5s %5s %6s %7s %4s %5s" % ("kernel", "VGPR", "SGPR", "vspill", "scratch", "occ", "LDS"))
+    # (sspill: scalar registers spilled into the lanes of a vector register -- every use inside a loop is a v_readlane; the walk
+    #  kernel lost 5 % to 62 of them before it got its forms by geometry, round 5)
+    print("%-70s %5s %5s %6s %6s %7s %4s %5s" % ("kernel", "VGPR", "SGPR", "sspill", "vspill", "scratch", "occ", "LDS"))
     for r, n in zip(rows, names):
         n = re.sub(r"^void cuberille::", "", n)
         n = re.sub(r"\(.*$", "", n)
         if flt and flt not in n:
             continue
-        print("%-70s %5s %5s %6s %7s %4s %5s" % (n[:70], r.get("VGPRs"), r.get("SGPRs"), r.get("VGPRs Spill"),
-                                                   r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"),
-                                                   r.get("LDS Size [bytes/block]")))
+        print("%-70s %5s %5s %6s %6s %7s %4s %5s" % (n[:70], r.get("VGPRs"), r.get("TotalSGPRs", r.get("SGPRs")), r.get("SGPRs Spill"),
+                                                       r.get("VGPRs Spill"), r.get("ScratchSize [bytes/lane]"),
+                                                       r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
 
 
 if __name__ == "__main__":
