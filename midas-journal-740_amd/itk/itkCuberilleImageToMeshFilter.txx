@@ -281,15 +281,16 @@ public:
   typedef typename TImage::PixelType PixelType;
   explicit HostGradient(const TImage *image)
   {
+    // (like the library since ABI 13: ITK's own origin and the region's start index -- the continuous index of a point is an INDEX,
+    //  a buffer position is that minus the start)
     const typename TImage::RegionType region = image->GetBufferedRegion();
-    typename TImage::PointType first;
-    image->TransformIndexToPhysicalPoint(region.GetIndex(), first);
     m_Buffer = image->GetBufferPointer();
     double i2p[9];
     for (int r = 0; r < 3; r++)
       {
       m_N[r] = static_cast<long>(region.GetSize()[r]);
-      m_Origin[r] = first[r];
+      m_Start[r] = static_cast<long>(region.GetIndex()[r]);
+      m_Origin[r] = image->GetOrigin()[r];
       m_Coef[r] = static_cast<float>(0.5 * (1.0 / image->GetSpacing()[r]));
       for (int c = 0; c < 3; c++)
         {
@@ -319,7 +320,8 @@ public:
       const double b = std::floor(ci);
       d[r] = ci - b;
       // the neighbour indices are clamped into the image (a NaN coordinate lands on index 0)
-      long bi = (b >= -1.0) ? ((b <= static_cast<double>(m_N[r])) ? static_cast<long>(b) : m_N[r]) : -1;
+      const double bl = b - static_cast<double>(m_Start[r]);                 // (exact: both are integers well inside 2^53)
+      long bi = (bl >= -1.0) ? ((bl <= static_cast<double>(m_N[r])) ? static_cast<long>(bl) : m_N[r]) : -1;
       if (!(b == b)) bi = 0;
       lo[r] = bi < 0 ? 0 : (bi > m_N[r] - 1 ? m_N[r] - 1 : bi);
       hi[r] = bi + 1 < 0 ? 0 : (bi + 1 > m_N[r] - 1 ? m_N[r] - 1 : bi + 1);
@@ -377,7 +379,7 @@ private:
       }
   }
   const PixelType *m_Buffer;
-  long m_N[3];
+  long m_N[3], m_Start[3];
   double m_Origin[3], m_Dir[9], m_P2I[9];
   float m_Coef[3];
 };
