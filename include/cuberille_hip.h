@@ -276,7 +276,9 @@ int cuberille_failed_row(void *host_row, size_t capacity, size_t *row_bytes);
 int cuberille_emit_points(cuberille_ctx *ctx);
 /* Slices a slab buffer must hold below own_z0 and above own_z1 (where the volume does not end) for these
  * parameters: 2 / 1 for the topology, and as far as the projection walk can carry a vertex -- step *
- * sum(relaxation^k, k <= max_steps+1) over the z spacing -- plus the interpolation cell and the gradient ring.
+ * sum(relaxation^k, k <= max_steps+1) over the z spacing, from where the walk STARTS: half a voxel under the lattice corner for an
+ * axis-aligned image, further under a tilted direction matrix (txx:266-270 take half a spacing off every PHYSICAL axis) -- plus
+ * the interpolation cell and the gradient ring.
  * cuberille_count returns CUBERILLE_ERR_HALO for a buffer that holds less.  Needs no GPU. */
 int cuberille_required_halo(const cuberille_image_desc *img, const cuberille_params *prm, int64_t *below, int64_t *above);
 /* The least a THIN_HALO slab must hold: 2 below / 1 above for the topology (the ghost slice own_z0 - 1 and the slice under
