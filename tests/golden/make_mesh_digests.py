@@ -69,6 +69,24 @@ def main():
     with open(os.path.join(HERE, "variant_digests.json"), "w") as f:
         json.dump(rows, f, indent=1)
     print(len(rows), "variant rows")
+    # Round 5: a LATER Update() of a filter object (quirk Q3, txx:484: the gradient interpolator of the first projecting update
+    # serves every later one -- cuberille_oracle_run_after, cuberille_hold_gradient) and a buffered region that starts at a
+    # non-zero index (cuberille_image_desc::index_start).  ORACLE output again: no reference fixture covers either.
+    names = sorted(iso_of)
+    rows = []
+    for i, name in enumerate(names):
+        vol = pkg.read_mha(os.path.join(HERE, "data", name))
+        first = pkg.read_mha(os.path.join(HERE, "data", names[(i + 3) % len(names)]))
+        kw = dict(triangles=1, project=1, threshold=0.5, step=0.25, relax=0.95, max_steps=50)
+        m = oracle.run(vol.voxels, iso_of[name], first=(first.voxels, first.spacing, first.origin, first.direction), **kw)
+        rows.append(dict(input=name, iso=iso_of[name], first=names[(i + 3) % len(names)], index_start=[0, 0, 0], **kw, **digest(m)))
+        start = [17 * (i + 1), -5 * i, 1000 + i]
+        m = oracle.run(vol.voxels, iso_of[name], spacing=(0.7, 1.3, 0.9), origin=(3.3, -2.1, 0.77), index_start=start, **kw)
+        rows.append(dict(input=name, iso=iso_of[name], first=None, index_start=start, spacing=[0.7, 1.3, 0.9], origin=[3.3, -2.1, 0.77],
+                         **kw, **digest(m)))
+    with open(os.path.join(HERE, "later_update_digests.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print(len(rows), "later-update / start-index rows")
 
 
 if __name__ == "__main__":

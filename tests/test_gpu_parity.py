@@ -284,6 +284,34 @@ def test_hip_path_reproduces_committed_variant_digests(pkg, extractor, volumes):
         assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
 
 
+def test_hip_path_reproduces_later_update_and_start_index_digests(pkg, volumes):
+    """tests/golden/later_update_digests.json (22 rows: every Data volume as a LATER update of a filter object whose first input
+    was another Data volume -- cuberille_hold_gradient -- and as a region that starts at a non-zero index -- index_start, ABI 13;
+    frozen oracle output): the HIP path gives the same bytes without the oracle in the loop."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "later_update_digests.json")))
+    ex = pkg.Extractor(0)
+    try:
+        for r in rows:
+            vol = volumes(r["input"])
+            prm = pkg.make_params(r["iso"], triangles=r["triangles"], project=r["project"], threshold=r["threshold"], step=r["step"],
+                                  relax=r["relax"], max_steps=r["max_steps"])
+            ex.hold_gradient(False)
+            if r["first"]:
+                ex.hold_gradient(True)
+                ex.extract_host(volumes(r["first"]), prm)
+                ex.extract_host(vol, prm)
+            else:
+                ex.extract_host(pkg.Volume(vol.voxels, spacing=r["spacing"], origin=r["origin"], index_start=r["index_start"]), prm)
+            mesh = ex.download()
+            assert (mesh.points.shape[0], mesh.cells.shape[0]) == (r["points"], r["cells"]), r["input"]
+            assert hashlib.sha256(_point_bytes(mesh.points)).hexdigest() == r["points_sha256"], r
+            assert hashlib.sha256(mesh.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r
+    finally:
+        ex.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_nonfinite_and_signed_zero_voxels_walk_like_the_oracle(pkg, oracle, extractor, dtype):
     """The projection shortens the gradient of a cell with finite taps to (-c)f(-1) + c f(+1) (equal to the

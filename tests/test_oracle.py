@@ -179,6 +179,28 @@ def test_oracle_reproduces_committed_variant_digests(pkg, oracle, volumes):
         assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
 
 
+def test_oracle_reproduces_later_update_and_start_index_digests(pkg, oracle, volumes):
+    """tests/golden/later_update_digests.json (round 5): a LATER Update() of a filter object -- quirk Q3, the walk along the first
+    input's gradient (cuberille_oracle_run_after) -- and a buffered region that starts at a non-zero index, frozen on every Data
+    volume: the restatements cannot drift, and the HIP path is held to the same bytes where only the fixtures travel."""
+    import hashlib
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "later_update_digests.json")))
+    assert len(rows) == 22
+    for r in rows:
+        vol = volumes(r["input"])
+        kw = dict(triangles=r["triangles"], project=r["project"], threshold=r["threshold"], step=r["step"], relax=r["relax"],
+                  max_steps=r["max_steps"])
+        if r["first"]:
+            f = volumes(r["first"])
+            m = oracle.run(vol.voxels, r["iso"], first=(f.voxels, f.spacing, f.origin, f.direction), **kw)
+        else:
+            m = oracle.run(vol.voxels, r["iso"], spacing=tuple(r["spacing"]), origin=tuple(r["origin"]), index_start=tuple(r["index_start"]), **kw)
+        assert (m.points.shape[0], m.cells.shape[0]) == (r["points"], r["cells"]), r["input"]
+        assert hashlib.sha256(_point_bytes(m.points)).hexdigest() == r["points_sha256"], (r["input"], r["first"], r["index_start"])
+        assert hashlib.sha256(m.cells.astype("<u8").tobytes()).hexdigest() == r["cells_sha256"], r["input"]
+
+
 def test_oracle_reproduces_bench_field_digests(pkg, oracle):
     """tests/golden/bench_field_digests.json (made by make_bench_field_digests.py): the oracle on the bench's own
     bit-portable fields is frozen too, so the checker of the GPU parity tests on those fields cannot drift."""
